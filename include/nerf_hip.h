@@ -1,0 +1,133 @@
+/*
+ * nerf_hip.h -- C ABI of libnerfhip.so, the MI355X (gfx950) implementation of NeRF's per-ray
+ * render core.
+ *
+ * The reference (sherwoac/nerf) is pure Python/TensorFlow and has no FFI; its boundary for this
+ * path is the Python call signatures of render()/render_rays()/create_nerf() and the helpers in
+ * run_nerf_helpers.py.  The package nerf_amd/ mirrors those signatures on torch tensors and
+ * binds the entry points below through ctypes.  Each entry point names the reference
+ * function(s) whose arithmetic it replaces (file:line under the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the parameter is documented
+ *     as "host"; the library allocates and frees nothing;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null
+ *     stream) and keeps no state between calls;
+ *   - all tensors are dense row-major fp32 unless stated; scalar camera parameters are double
+ *     because the reference forms constants such as -1/(W/(2*focal)) in Python doubles before
+ *     rounding them to fp32;
+ *   - the return value is 0 on success, a negative NERF_E_* code for a rejected argument, or a
+ *     positive hipError_t; nerf_last_error() returns a thread-local message for the last
+ *     non-zero return.
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_ABI_VERSION 1
+
+#define NERF_E_ARG (-1)        /* null pointer / non-positive size / unsupported width      */
+#define NERF_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for              */
+
+typedef void* nerf_stream_t;
+
+int nerf_abi_version(void);
+const char* nerf_last_error(void);
+
+/* ---- ray generation --------------------------------------------------------------------- */
+
+/* get_rays / get_rays_np (run_nerf_helpers.py:122-129, :135-142).
+ * c2w: HOST pointer to 12 floats, the row-major [3,4] camera-to-world matrix.
+ * rays_o, rays_d: [H,W,3].  No half-pixel offset; directions are not normalised. */
+int nerf_get_rays(int H, int W, double focal, const float* c2w, float* rays_o, float* rays_d,
+                  nerf_stream_t stream);
+
+/* ndc_rays (run_nerf_helpers.py:145-180), same operation order.  In/out [n,3]; out may alias in. */
+int nerf_ndc_rays(int64_t n, int H, int W, double focal, double near, const float* rays_o,
+                  const float* rays_d, float* out_o, float* out_d, nerf_stream_t stream);
+
+/* render()'s ray-batch assembly (run_nerf.py:79-108): viewdirs = view_src/||view_src|| taken
+ * before NDC, optional NDC projection with near plane 1, then
+ * out[i] = [o(3), d(3), near, far, (viewdirs(3))], width = 8 or 11.
+ * view_src: [n,3] or NULL (width 8).  near_arr/far_arr: per-ray [n] or NULL -> scalars. */
+int nerf_build_ray_batch(int64_t n, const float* rays_o, const float* rays_d,
+                         const float* view_src, int ndc, int H, int W, double focal,
+                         const float* near_arr, const float* far_arr, double near, double far,
+                         float* out, int width, nerf_stream_t stream);
+
+/* ---- positional encoding (standalone form) ------------------------------------------------ */
+
+/* Embedder.embed (run_nerf_helpers.py:22-56): out[m, 3+6L] = [x, sin(x 2^0), cos(x 2^0), ...]. */
+int nerf_embed(int64_t m, const float* x, int L, float* out, nerf_stream_t stream);
+
+/* ---- depth sampling ----------------------------------------------------------------------- */
+
+/* render_rays' stratified depths (NERFCO.nerf_renderer.render_rays, source absent from the
+ * reference tree; in-tree twin tiny_nerf.ipynb "z_vals = tf.linspace(near, far, N_samples)").
+ * rays: [n,width] ray batch (near at column 6, far at 7).  perturb_u: [n,S] uniforms in [0,1)
+ * or NULL (no jitter).  z_out: [n,S]. */
+int nerf_sample_z(int64_t n, int S, const float* rays, int width, int lindisp,
+                  const float* perturb_u, float* z_out, nerf_stream_t stream);
+
+/* ---- the MLP ------------------------------------------------------------------------------ */
+
+/* Size in bytes of the packed fp16 weight stream + fp32 biases one network occupies. */
+size_t nerf_mlp_packed_bytes(void);
+
+/* Re-lays one init_nerf_model(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4],
+ * use_viewdirs=True) network (run_nerf_helpers.py:80-117) into the MFMA fragment stream the
+ * forward kernel consumes.  params: HOST array of 24 device pointers in get_weights() order --
+ * kernel [in,out] and bias [out] of the 8 point layers, bottleneck, view layer, rgb, alpha. */
+int nerf_mlp_pack(const float* const* params, void* packed, nerf_stream_t stream);
+
+/* run_network + the Keras model call (run_nerf.py:209-214; run_nerf_helpers.py:22-56, :89-112,
+ * :216-223) with the query points formed on the fly as o + d*z (render_rays).  Positional
+ * encoding (L=10 points, L=4 view directions) is computed in-kernel; matmuls are fp16 MFMA with
+ * fp32 accumulation.  rays [n_rays,width>=11], z [n_rays,S] -> raw [n_rays,S,4] = (r,g,b,sigma)
+ * pre-activation. */
+int nerf_mlp_forward_rays(const void* packed, const float* rays, int width, const float* z,
+                          int64_t n_rays, int S, float* raw, nerf_stream_t stream);
+
+/* Same network on explicit points: network_query_fn(inputs[n,S,3], viewdirs[n,3], network_fn)
+ * (run_nerf.py:209-214; extract_mesh.ipynb "raw = net_fn(...)") -> raw [n,S,4]. */
+int nerf_mlp_forward_pts(const void* packed, const float* pts, const float* viewdirs,
+                         int64_t n, int S, float* raw, nerf_stream_t stream);
+
+/* ---- compositing -------------------------------------------------------------------------- */
+
+/* raw2outputs (NERFCO.nerf_renderer, source absent; in-tree core lines tiny_nerf.ipynb
+ * render_rays cell: sigma = relu(raw[...,3]), rgb = sigmoid(raw[...,:3]), dists, alpha,
+ * weights = alpha * exclusive cumprod(1-alpha+1e-10), rgb/depth/acc maps), plus upstream's
+ * dists *= ||rays_d||, disp = 1/max(1e-10, depth/acc) and the white-background add.
+ * rays_d is read at rays_d[i*d_stride + 0..2].  noise: [n,S] standard normal or NULL.
+ * Any output pointer except rgb_map may be NULL. */
+int nerf_composite_fwd(const float* raw, const float* z, const float* rays_d, int d_stride,
+                       int64_t n, int S, int white_bkgd, const float* noise, float noise_std,
+                       float* rgb_map, float* disp_map, float* acc_map, float* depth_map,
+                       float* weights, nerf_stream_t stream);
+
+/* ---- hierarchical resampling -------------------------------------------------------------- */
+
+/* sample_pdf (run_nerf_helpers.py:185-213).  bins [n,nb], weights [n,nb-1] -> samples [n,ns].
+ * det != 0: u = linspace(0,1,ns); else u: [n,ns] uniforms supplied by the caller. */
+int nerf_sample_pdf(const float* bins, const float* weights, int64_t n, int nb, int ns, int det,
+                    const float* u, float* samples, nerf_stream_t stream);
+
+/* render_rays' resampling step: z_mid = .5(z[1:]+z[:-1]); z_samples = sample_pdf(z_mid,
+ * weights[:,1:-1], Si, det); z_out = sort(concat(z_vals, z_samples)); z_std = std(z_samples).
+ * z_vals, weights: [n,Sc] (z_vals ascending); z_out: [n,Sc+Si]; z_samples [n,Si] and z_std [n]
+ * may be NULL.  With det == 0, u [n,Si] must be given; the kernel sorts the samples itself. */
+int nerf_resample_merge(const float* z_vals, const float* weights, int64_t n, int Sc, int Si,
+                        int det, const float* u, float* z_out, float* z_samples, float* z_std,
+                        nerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

@@ -1,0 +1,80 @@
+// Shared helpers for libnerfhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/nerf_hip.h"
+
+#define NERF_API extern "C" __attribute__((visibility("default")))
+
+namespace nerf {
+
+void set_error(const char* fmt, ...);
+
+// Records the message and returns the code (used as `return fail(NERF_E_ARG, "...")`).
+#define NERF_FAIL(code, ...) (nerf::set_error(__VA_ARGS__), (code))
+
+#define NERF_REQUIRE(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) return NERF_FAIL(NERF_E_ARG, __VA_ARGS__);   \
+    } while (0)
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+inline hipStream_t as_stream(nerf_stream_t s) { return (hipStream_t)s; }
+
+constexpr int kWave = 64;
+
+// Sum / product across the 64 lanes of a wave; every lane gets the result.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float old, float src) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                           CTRL, ROW_MASK, 0xf, false));
+}
+
+// Inclusive product scan over the wave's 64 lanes (lane i gets v0*...*vi).
+__device__ __forceinline__ float wave_scan_mul(float v) {
+    v *= dpp_or<0x111, 0xf>(1.0f, v);  // row_shr:1
+    v *= dpp_or<0x112, 0xf>(1.0f, v);  // row_shr:2
+    v *= dpp_or<0x114, 0xf>(1.0f, v);  // row_shr:4
+    v *= dpp_or<0x118, 0xf>(1.0f, v);  // row_shr:8
+    v *= dpp_or<0x142, 0xa>(1.0f, v);  // row_bcast:15 -> rows 1 and 3
+    v *= dpp_or<0x143, 0xc>(1.0f, v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// Inclusive sum scan, same shape.
+__device__ __forceinline__ float wave_scan_add(float v) {
+    v += dpp_or<0x111, 0xf>(0.0f, v);
+    v += dpp_or<0x112, 0xf>(0.0f, v);
+    v += dpp_or<0x114, 0xf>(0.0f, v);
+    v += dpp_or<0x118, 0xf>(0.0f, v);
+    v += dpp_or<0x142, 0xa>(0.0f, v);
+    v += dpp_or<0x143, 0xc>(0.0f, v);
+    return v;
+}
+
+// Lane i gets lane i-1's value; lane 0 gets `first`.
+__device__ __forceinline__ float wave_shr1(float first, float v) {
+    return dpp_or<0x138, 0xf>(first, v);  // wave_shr:1
+}
+
+__device__ __forceinline__ float lane63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+}  // namespace nerf

@@ -1,0 +1,89 @@
+// Alpha compositing along each ray (raw2outputs) as a wavefront-scan kernel: one 64-lane wave
+// per ray, one sample per lane per 64-sample chunk, exclusive transmittance product by a DPP
+// scan carried across chunks.  HBM-bound: raw (16 B/sample) and z (4 B/sample) are read once
+// as coalesced 1 KiB / 256 B wave transactions, weights written once.
+#include "common.h"
+
+namespace nerf {
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
+    const float4* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d,
+    int d_stride, int64_t n, int S, int white_bkgd, const float* __restrict__ noise,
+    float noise_std, float* __restrict__ rgb_map, float* __restrict__ disp_map,
+    float* __restrict__ acc_map, float* __restrict__ depth_map, float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t ray = wave0; ray < n; ray += nwaves) {
+        const float dx = rays_d[ray * d_stride], dy = rays_d[ray * d_stride + 1],
+                    dz = rays_d[ray * d_stride + 2];
+        const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const int64_t row = ray * S;
+        float carry = 1.0f;
+        float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+        for (int base = 0; base < S; base += 64) {
+            const int s = base + lane;
+            const bool valid = s < S;
+            float4 r = valid ? raw[row + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float zz = valid ? z[row + s] : 0.f;
+            float dist = (s + 1 < S) ? z[row + s + 1] - zz : 1e10f;
+            dist = dist * norm;
+            float sig = r.w;
+            if (noise) sig = sig + (valid ? noise[row + s] : 0.f) * noise_std;
+            const float alpha = valid ? 1.0f - __expf(-fmaxf(sig, 0.f) * dist) : 0.f;
+            const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
+            const float incl = wave_scan_mul(t);
+            const float trans = carry * wave_shr1(1.0f, incl);
+            const float w = alpha * trans;
+            carry = carry * lane63(incl);
+            if (valid) {
+                if (weights) weights[row + s] = w;
+                sr += w * sigmoidf(r.x);
+                sg += w * sigmoidf(r.y);
+                sb += w * sigmoidf(r.z);
+                sd += w * zz;
+                sa += w;
+            }
+        }
+        sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sd = wave_sum(sd),
+        sa = wave_sum(sa);
+        if (lane == 0) {
+            // disp = 1/max(1e-10, depth/acc); 0/0 stays NaN as in the reference's maximum().
+            const float q = sd / sa;
+            const float disp = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+            if (white_bkgd) {
+                const float bg = 1.0f - sa;
+                sr += bg, sg += bg, sb += bg;
+            }
+            rgb_map[ray * 3] = sr, rgb_map[ray * 3 + 1] = sg, rgb_map[ray * 3 + 2] = sb;
+            if (disp_map) disp_map[ray] = disp;
+            if (acc_map) acc_map[ray] = sa;
+            if (depth_map) depth_map[ray] = sd;
+        }
+    }
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+NERF_API int nerf_composite_fwd(const float* raw, const float* z, const float* rays_d,
+                                int d_stride, int64_t n, int S, int white_bkgd,
+                                const float* noise, float noise_std, float* rgb_map,
+                                float* disp_map, float* acc_map, float* depth_map, float* weights,
+                                nerf_stream_t stream) {
+    NERF_REQUIRE(raw && z && rays_d && rgb_map, "nerf_composite_fwd: null pointer");
+    NERF_REQUIRE(n >= 0 && S > 0 && d_stride >= 3, "nerf_composite_fwd: bad size (n=%lld S=%d d_stride=%d)",
+                 (long long)n, S, d_stride);
+    NERF_REQUIRE(((uintptr_t)raw & 15) == 0, "nerf_composite_fwd: raw must be 16-byte aligned");
+    if (n == 0) return 0;
+    if (noise_std <= 0.f) noise = nullptr;
+    const int64_t want = (n + 3) / 4;
+    const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
+    composite_fwd_kernel<<<blocks, 256, 0, as_stream(stream)>>>(
+        (const float4*)raw, z, rays_d, d_stride, n, S, white_bkgd, noise, noise_std, rgb_map,
+        disp_map, acc_map, depth_map, weights);
+    return check_launch("nerf_composite_fwd");
+}

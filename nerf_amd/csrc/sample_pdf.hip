@@ -1,0 +1,210 @@
+// Hierarchical inverse-CDF resampling (sample_pdf) and the sorted merge with the coarse depths,
+// one 64-lane wave per ray.  The ray's CDF and bin edges live in the wave's slice of LDS; every
+// lane inverts the CDF for its own samples by binary search (searchsorted side='right'), and the
+// two sorted depth lists are merged by rank (each element's output slot = its own index + the
+// count of elements of the other list that precede it), so no general sort is needed when the
+// uniforms are the deterministic linspace.  With caller-supplied random uniforms the samples
+// are first sorted in LDS by a bitonic network.  HBM traffic: z and weights read once
+// (coalesced), merged depths written once.
+#include "common.h"
+
+namespace nerf {
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // One wave's LDS operations execute in issue order; this only drains them and stops the
+    // compiler from moving LDS accesses across the point.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct PdfArgs {
+    // merge mode: z_vals/weights are [n,Sc]; direct mode: bins [n,nb], weights [n,nb-1]
+    const float* bins_or_z;
+    const float* weights;
+    const float* u;
+    float* samples;  // [n,ns] or null
+    float* z_out;    // [n,Sc+ns] (merge mode) or null
+    float* z_std;    // [n] or null
+    int64_t n;
+    int nb;       // number of bin edges (= Sc-1 in merge mode)
+    int ns;       // samples to draw
+    int ns_pow2;  // ns rounded up to a power of two (bitonic network size)
+    int Sc;       // coarse depth count (merge mode), 0 in direct mode
+    int det;
+    int lds_floats_per_wave;
+};
+
+template <bool MERGE>
+__global__ __launch_bounds__(256) void sample_pdf_kernel(PdfArgs a) {
+    extern __shared__ float lds_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    float* cdf = lds_all + (size_t)wave_in_block * a.lds_floats_per_wave;
+    float* bins = cdf + a.nb;
+    float* sA = bins + a.nb;                  // [Sc]      (merge mode)
+    float* sB = sA + (MERGE ? a.Sc : 0);      // [ns_pow2]
+    float* sOut = sB + a.ns_pow2;             // [Sc+ns]   (merge mode)
+    const int nb = a.nb, nw = a.nb - 1, ns = a.ns, Sc = a.Sc;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+
+    for (int64_t ray = wave0; ray < a.n; ray += nwaves) {
+        // ---- stage bins (and the coarse depths) in LDS; weights + 1e-5 and their sum ----
+        const float* wsrc;
+        if (MERGE) {
+            const float* zr = a.bins_or_z + ray * Sc;
+            for (int i = lane; i < Sc; i += 64) {
+                const float zi = zr[i];
+                sA[i] = zi;
+                if (i + 1 < Sc) bins[i] = 0.5f * (zr[i + 1] + zi);  // z_mid
+            }
+            wsrc = a.weights + ray * Sc + 1;  // weights[:, 1:-1]
+        } else {
+            const float* br = a.bins_or_z + ray * nb;
+            for (int i = lane; i < nb; i += 64) bins[i] = br[i];
+            wsrc = a.weights + ray * nw;
+        }
+        float part = 0.f;
+        for (int i = lane; i < nw; i += 64) part += wsrc[i] + 1e-5f;
+        const float total = wave_sum(part);
+        // ---- cdf = [0, cumsum(w/total)] ----
+        float carry = 0.f;
+        if (lane == 0) cdf[0] = 0.f;
+        for (int base = 0; base < nw; base += 64) {
+            const int i = base + lane;
+            const float p = (i < nw) ? (wsrc[i] + 1e-5f) / total : 0.f;
+            const float incl = wave_scan_add(p);
+            if (i < nw) cdf[i + 1] = carry + incl;
+            carry = carry + lane63(incl);
+        }
+        wave_lds_sync();
+        // ---- invert the CDF ----
+        float ssum = 0.f;
+        for (int k = lane; k < a.ns_pow2; k += 64) {
+            float smp = __builtin_inff();  // padding of the sort network
+            if (k < ns) {
+                const float u = a.det ? ((ns > 1) ? (float)k / (float)(ns - 1) : 0.f)
+                                      : a.u[ray * ns + k];
+                int lo = 0, hi = nb;  // first index with cdf[idx] > u
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+                }
+                const int below = max(0, lo - 1), above = min(nb - 1, lo);
+                const float c0 = cdf[below], c1 = cdf[above];
+                float denom = c1 - c0;
+                if (denom < 1e-5f) denom = 1.0f;
+                const float t = (u - c0) / denom;
+                const float b0 = bins[below], b1 = bins[above];
+                smp = b0 + t * (b1 - b0);
+                if (a.samples) a.samples[ray * ns + k] = smp;
+                ssum += smp;
+            }
+            sB[k] = smp;
+        }
+        if (a.z_std) {
+            const float mean = wave_sum(ssum) / (float)ns;
+            wave_lds_sync();
+            float v = 0.f;
+            for (int k = lane; k < ns; k += 64) {
+                const float d = sB[k] - mean;
+                v += d * d;
+            }
+            v = wave_sum(v);
+            if (lane == 0) a.z_std[ray] = sqrtf(v / (float)ns);
+        }
+        if (MERGE) {
+            wave_lds_sync();
+            if (!a.det) {
+                // bitonic sort of sB[0..ns_pow2) ascending (padding is +inf)
+                const int P = a.ns_pow2;
+                for (int k = 2; k <= P; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int t = lane; t < (P >> 1); t += 64) {
+                            const int i = 2 * j * (t / j) + (t % j);
+                            const float x = sB[i], y = sB[i + j];
+                            const bool up = (i & k) == 0;
+                            if ((x > y) == up) { sB[i] = y; sB[i + j] = x; }
+                        }
+                        wave_lds_sync();
+                    }
+                }
+            }
+            // rank merge: ties put the coarse depth first
+            for (int i = lane; i < Sc; i += 64) {
+                const float v = sA[i];
+                int lo = 0, hi = ns;  // count of samples < v
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sB[mid] < v) lo = mid + 1; else hi = mid;
+                }
+                sOut[i + lo] = v;
+            }
+            for (int j = lane; j < ns; j += 64) {
+                const float v = sB[j];
+                int lo = 0, hi = Sc;  // count of coarse depths <= v
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sA[mid] <= v) lo = mid + 1; else hi = mid;
+                }
+                sOut[j + lo] = v;
+            }
+            wave_lds_sync();
+            float* zo = a.z_out + ray * (int64_t)(Sc + ns);
+            for (int i = lane; i < Sc + ns; i += 64) zo[i] = sOut[i];
+        }
+        wave_lds_sync();  // LDS slice is reused by the wave's next ray
+    }
+}
+
+static int launch_pdf(PdfArgs a, bool merge, hipStream_t st, const char* what) {
+    int p2 = 1;
+    while (p2 < a.ns) p2 <<= 1;
+    a.ns_pow2 = p2;
+    a.lds_floats_per_wave = 2 * a.nb + p2 + (merge ? (2 * a.Sc + a.ns) : 0);
+    const size_t per_wave = (size_t)a.lds_floats_per_wave * sizeof(float);
+    int waves = 4;
+    while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+    if (per_wave * waves > 64 * 1024)
+        return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: %d bins / %d samples need %zu B of LDS per ray (max 65536)",
+                         what, a.nb, a.ns, per_wave);
+    const int64_t want = (a.n + waves - 1) / waves;
+    const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
+    if (merge)
+        sample_pdf_kernel<true><<<blocks, waves * 64, per_wave * waves, st>>>(a);
+    else
+        sample_pdf_kernel<false><<<blocks, waves * 64, per_wave * waves, st>>>(a);
+    return check_launch(what);
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+NERF_API int nerf_sample_pdf(const float* bins, const float* weights, int64_t n, int nb, int ns,
+                             int det, const float* u, float* samples, nerf_stream_t stream) {
+    NERF_REQUIRE(bins && weights && samples, "nerf_sample_pdf: null pointer");
+    NERF_REQUIRE(n >= 0 && nb >= 2 && ns >= 1, "nerf_sample_pdf: bad size (n=%lld nb=%d ns=%d)",
+                 (long long)n, nb, ns);
+    NERF_REQUIRE(det || u, "nerf_sample_pdf: det == 0 needs the uniforms u");
+    if (n == 0) return 0;
+    PdfArgs a{};
+    a.bins_or_z = bins, a.weights = weights, a.u = u, a.samples = samples;
+    a.n = n, a.nb = nb, a.ns = ns, a.Sc = 0, a.det = det;
+    return launch_pdf(a, false, as_stream(stream), "nerf_sample_pdf");
+}
+
+NERF_API int nerf_resample_merge(const float* z_vals, const float* weights, int64_t n, int Sc,
+                                 int Si, int det, const float* u, float* z_out, float* z_samples,
+                                 float* z_std, nerf_stream_t stream) {
+    NERF_REQUIRE(z_vals && weights && z_out, "nerf_resample_merge: null pointer");
+    NERF_REQUIRE(n >= 0 && Sc >= 3 && Si >= 1, "nerf_resample_merge: bad size (n=%lld Sc=%d Si=%d)",
+                 (long long)n, Sc, Si);
+    NERF_REQUIRE(det || u, "nerf_resample_merge: det == 0 needs the uniforms u");
+    if (n == 0) return 0;
+    PdfArgs a{};
+    a.bins_or_z = z_vals, a.weights = weights, a.u = u, a.samples = z_samples, a.z_out = z_out,
+    a.z_std = z_std;
+    a.n = n, a.nb = Sc - 1, a.ns = Si, a.Sc = Sc, a.det = det;
+    return launch_pdf(a, true, as_stream(stream), "nerf_resample_merge");
+}

@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the C ABI: torch tensors in, torch tensors out, on the current HIP
+stream.  Shape checks live here (the kernels trust their arguments); arithmetic lives in the
+library.  Nothing in this module computes on the CPU."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as nv
+
+
+def _dev(t=None):
+    if t is not None and isinstance(t, torch.Tensor) and t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise nv.NerfHipError("no GPU visible: nerf_amd runs on MI355X only (there is no CPU path)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def get_rays(H, W, focal, c2w):
+    """run_nerf_helpers.py:122-129 -> rays_o, rays_d as [H,W,3] fp32 tensors."""
+    dev = _dev(c2w if isinstance(c2w, torch.Tensor) else None)
+    m = np.ascontiguousarray(torch.as_tensor(c2w).detach().cpu().numpy()[:3, :4], dtype=np.float32)
+    rays_o = torch.empty((int(H), int(W), 3), dtype=torch.float32, device=dev)
+    rays_d = torch.empty_like(rays_o)
+    with torch.cuda.device(dev):
+        nv.check(nv.lib().nerf_get_rays(int(H), int(W), float(focal),
+                                        m.ctypes.data_as(ctypes.c_void_p), nv.ptr(rays_o),
+                                        nv.ptr(rays_d), nv.stream()), "nerf_get_rays")
+    return rays_o, rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """run_nerf_helpers.py:145-180 on [...,3] tensors."""
+    o = nv.f32(rays_o)
+    d = nv.f32(rays_d, o.device)
+    if o.shape != d.shape or o.shape[-1] != 3:
+        raise ValueError(f"ndc_rays: rays_o {tuple(o.shape)} and rays_d {tuple(d.shape)} must both be [...,3]")
+    oo, od = torch.empty_like(o), torch.empty_like(d)
+    with torch.cuda.device(o.device):
+        nv.check(nv.lib().nerf_ndc_rays(o.numel() // 3, int(H), int(W), float(focal), float(near),
+                                        nv.ptr(o), nv.ptr(d), nv.ptr(oo), nv.ptr(od), nv.stream()),
+                 "nerf_ndc_rays")
+    return oo, od
+
+
+def build_ray_batch(rays_o, rays_d, view_src, ndc, H, W, focal, near, far):
+    """render()'s assembly of the [N, 8|11] ray batch (run_nerf.py:79-108).
+    near/far: python scalars or per-ray tensors [N] / [N,1]."""
+    o = nv.f32(rays_o).reshape(-1, 3)
+    d = nv.f32(rays_d, o.device).reshape(-1, 3)
+    n = o.shape[0]
+    if d.shape[0] != n:
+        raise ValueError("build_ray_batch: rays_o and rays_d disagree on the ray count")
+    v = None
+    if view_src is not None:
+        v = nv.f32(view_src, o.device).reshape(-1, 3)
+        if v.shape[0] != n:
+            raise ValueError("build_ray_batch: view directions disagree on the ray count")
+    width = 11 if v is not None else 8
+    near_t = far_t = None
+    near_s = far_s = 0.0
+    if isinstance(near, (torch.Tensor, np.ndarray)) and isinstance(far, (torch.Tensor, np.ndarray)):
+        near_t = nv.f32(near, o.device).reshape(-1)
+        far_t = nv.f32(far, o.device).reshape(-1)
+        if near_t.numel() != n or far_t.numel() != n:
+            raise ValueError("build_ray_batch: per-ray near/far must have one value per ray")
+    else:
+        near_s, far_s = float(near), float(far)
+    out = torch.empty((n, width), dtype=torch.float32, device=o.device)
+    with torch.cuda.device(o.device):
+        nv.check(nv.lib().nerf_build_ray_batch(n, nv.ptr(o), nv.ptr(d), nv.ptr(v), int(bool(ndc)),
+                                               int(H), int(W), float(focal), nv.ptr(near_t),
+                                               nv.ptr(far_t), near_s, far_s, nv.ptr(out), width,
+                                               nv.stream()), "nerf_build_ray_batch")
+    return out
+
+
+def embed(x, L):
+    """Embedder.embed (run_nerf_helpers.py:22-56) on [...,3] -> [..., 3+6L]."""
+    x = nv.f32(x)
+    if x.shape[-1] != 3:
+        raise ValueError("embed: last dimension must be 3")
+    out = torch.empty(tuple(x.shape[:-1]) + (3 + 6 * L,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().nerf_embed(x.numel() // 3, nv.ptr(x), int(L), nv.ptr(out), nv.stream()),
+                 "nerf_embed")
+    return out
+
+
+def sample_z(rays, S, lindisp=False, perturb_u=None):
+    """Stratified depths [N,S] for a ray batch [N,width>=8]."""
+    rays = nv.f32(rays)
+    n, width = rays.shape
+    u = None
+    if perturb_u is not None:
+        u = nv.f32(perturb_u, rays.device)
+        if tuple(u.shape) != (n, S):
+            raise ValueError(f"sample_z: perturb_u must be [{n},{S}]")
+    z = torch.empty((n, S), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        nv.check(nv.lib().nerf_sample_z(n, int(S), nv.ptr(rays), width, int(bool(lindisp)),
+                                        nv.ptr(u), nv.ptr(z), nv.stream()), "nerf_sample_z")
+    return z
+
+
+def packed_bytes():
+    return int(nv.lib().nerf_mlp_packed_bytes())
+
+
+def mlp_pack(params, packed):
+    """params: 24 contiguous fp32 CUDA tensors in get_weights() order; packed: uint8 [packed_bytes()]."""
+    arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
+    with torch.cuda.device(packed.device):
+        nv.check(nv.lib().nerf_mlp_pack(arr, nv.ptr(packed), nv.stream()), "nerf_mlp_pack")
+
+
+def mlp_forward_rays(packed, rays, z):
+    """raw [N,S,4] for points o + d*z of a ray batch [N,11] with depths z [N,S]."""
+    n, width = rays.shape
+    S = z.shape[1]
+    if z.shape[0] != n:
+        raise ValueError("mlp_forward_rays: rays and z disagree on the ray count")
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
+    with torch.cuda.device(rays.device):
+        nv.check(nv.lib().nerf_mlp_forward_rays(nv.ptr(packed), nv.ptr(rays), width, nv.ptr(z), n, S,
+                                                nv.ptr(raw), nv.stream()), "nerf_mlp_forward_rays")
+    return raw
+
+
+def mlp_forward_pts(packed, pts, viewdirs):
+    """raw [N,S,4] for explicit points [N,S,3] and per-ray view directions [N,3]."""
+    n, S = pts.shape[0], pts.shape[1]
+    if tuple(viewdirs.shape) != (n, 3) or pts.shape[2] != 3:
+        raise ValueError("mlp_forward_pts: need pts [N,S,3] and viewdirs [N,3]")
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        nv.check(nv.lib().nerf_mlp_forward_pts(nv.ptr(packed), nv.ptr(pts), nv.ptr(viewdirs), n, S,
+                                               nv.ptr(raw), nv.stream()), "nerf_mlp_forward_pts")
+    return raw
+
+
+def composite_fwd(raw, z, rays_d, d_stride, white_bkgd=False, noise=None, noise_std=0.0,
+                  want_weights=True):
+    """raw2outputs.  rays_d is any fp32 tensor whose row i starts the direction of ray i when read
+    with stride d_stride (e.g. the ray batch offset by 3 columns)."""
+    n, S = z.shape
+    dev = z.device
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    weights = torch.empty((n, S), dtype=torch.float32, device=dev) if want_weights else None
+    with torch.cuda.device(dev):
+        nv.check(nv.lib().nerf_composite_fwd(nv.ptr(raw), nv.ptr(z), ctypes.c_void_p(rays_d.data_ptr()),
+                                             int(d_stride), n, S, int(bool(white_bkgd)),
+                                             nv.ptr(noise), float(noise_std), nv.ptr(rgb),
+                                             nv.ptr(disp), nv.ptr(acc), nv.ptr(depth),
+                                             nv.ptr(weights), nv.stream()), "nerf_composite_fwd")
+    return rgb, disp, acc, weights, depth
+
+
+def sample_pdf(bins, weights, N_samples, det=False, u=None):
+    """run_nerf_helpers.py:185-213 on [...,nb] bins and [...,nb-1] weights."""
+    bins = nv.f32(bins)
+    weights = nv.f32(weights, bins.device)
+    nb = bins.shape[-1]
+    if weights.shape[-1] != nb - 1 or weights.shape[:-1] != bins.shape[:-1]:
+        raise ValueError(f"sample_pdf: bins {tuple(bins.shape)} need weights [..., {nb - 1}]")
+    lead = tuple(bins.shape[:-1])
+    n = bins.numel() // nb
+    if not det:
+        if u is None:
+            u = torch.rand(lead + (N_samples,), dtype=torch.float32, device=bins.device)
+        u = nv.f32(u, bins.device)
+        if tuple(u.shape) != lead + (N_samples,):
+            raise ValueError("sample_pdf: u must be [..., N_samples]")
+    else:
+        u = None
+    out = torch.empty(lead + (N_samples,), dtype=torch.float32, device=bins.device)
+    with torch.cuda.device(bins.device):
+        nv.check(nv.lib().nerf_sample_pdf(nv.ptr(bins), nv.ptr(weights), n, nb, int(N_samples),
+                                          int(bool(det)), nv.ptr(u), nv.ptr(out), nv.stream()),
+                 "nerf_sample_pdf")
+    return out
+
+
+def resample_merge(z_vals, weights, N_importance, det=True, u=None, want_samples=True):
+    """z_mid -> sample_pdf(weights[:,1:-1]) -> sort(concat) of render_rays, one kernel.
+    Returns z_fine [N,Sc+Si], z_samples [N,Si] (or None), z_std [N]."""
+    n, Sc = z_vals.shape
+    dev = z_vals.device
+    if tuple(weights.shape) != (n, Sc):
+        raise ValueError("resample_merge: weights must match z_vals")
+    if not det:
+        if u is None:
+            u = torch.rand((n, N_importance), dtype=torch.float32, device=dev)
+        u = nv.f32(u, dev)
+        if tuple(u.shape) != (n, N_importance):
+            raise ValueError("resample_merge: u must be [N, N_importance]")
+    else:
+        u = None
+    z_out = torch.empty((n, Sc + N_importance), dtype=torch.float32, device=dev)
+    z_samples = torch.empty((n, N_importance), dtype=torch.float32, device=dev) if want_samples else None
+    z_std = torch.empty((n,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nv.check(nv.lib().nerf_resample_merge(nv.ptr(z_vals), nv.ptr(weights), n, Sc,
+                                              int(N_importance), int(bool(det)), nv.ptr(u),
+                                              nv.ptr(z_out), nv.ptr(z_samples), nv.ptr(z_std),
+                                              nv.stream()), "nerf_resample_merge")
+    return z_out, z_samples, z_std

@@ -1,0 +1,182 @@
+"""Drop-in counterparts of the reference's run_nerf_helpers.py on torch (ROCm) tensors.
+
+Same names, argument meaning and return structure as the reference (file:line cited per
+function), so `from nerf_amd.run_nerf_helpers import *` can replace the reference's star import
+(run_nerf.py:7).  All arithmetic runs in libnerfhip.so on the GPU.
+"""
+import numpy as np
+import torch
+
+from . import _native as nv
+from . import ops
+
+__all__ = ["img2mse", "mse2psnr", "to8b", "Embedder", "get_embedder", "NerfModel", "init_nerf_model",
+           "get_rays", "get_rays_np", "ndc_rays", "sample_pdf", "batchify"]
+
+
+# ---- misc (run_nerf_helpers.py:11-17) ----------------------------------------------------------
+def img2mse(x, y):
+    """run_nerf_helpers.py:11"""
+    return torch.mean(torch.square(x - y))
+
+
+def mse2psnr(x):
+    """run_nerf_helpers.py:14"""
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x, dtype=torch.float32)
+    return -10. * torch.log(x) / float(np.log(10.))
+
+
+def to8b(x):
+    """run_nerf_helpers.py:17 (NumPy in, uint8 out, as in the reference)."""
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+# ---- positional encoding (run_nerf_helpers.py:22-75) -------------------------------------------
+class Embedder:
+    """Same constructor keywords as the reference (:24-53).  Only the configuration the reference
+    itself ever builds is accepted: 3 input dims, include_input, log-sampled 2^k frequencies and
+    (sin, cos) -- that is what the kernels encode."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        d = kwargs.get('input_dims', 3)
+        n = kwargs['num_freqs']
+        if d != 3 or not kwargs.get('include_input', True) or not kwargs.get('log_sampling', True) \
+                or kwargs.get('max_freq_log2', n - 1) != n - 1:
+            raise NotImplementedError("Embedder: only include_input=True, input_dims=3, "
+                                      "log_sampling=True, max_freq_log2=num_freqs-1 is built")
+        self.num_freqs = n
+        self.out_dim = d + 2 * d * n
+
+    def embed(self, inputs):
+        return ops.embed(inputs, self.num_freqs)
+
+
+def get_embedder(multires, i=0):
+    """run_nerf_helpers.py:59-75 -> (embed_fn, out_dim)."""
+    if i == -1:
+        return (lambda x: x), 3
+    eo = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                  log_sampling=True, periodic_fns=['sin', 'cos'])
+
+    def embed(x, eo=eo):
+        return eo.embed(x)
+    embed.multires = multires
+    return embed, eo.out_dim
+
+
+# ---- model (run_nerf_helpers.py:80-117) --------------------------------------------------------
+class NerfModel:
+    """What init_nerf_model returns: the parameters of one network with the slice of the Keras
+    Model interface create_nerf and train() use (get_weights / set_weights / trainable_variables,
+    run_nerf.py:181,:253,:841), plus the packed fp16 stream the MFMA kernels read.
+
+    Parameter order (get_weights()): kernel [in,out], bias [out] of the D point layers, then
+    bottleneck, view layer, rgb, alpha."""
+
+    def __init__(self, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, device=None,
+                 generator=None):
+        if not (D == 8 and W == 256 and input_ch == 63 and input_ch_views == 27
+                and tuple(skips) == (4,) and use_viewdirs and output_ch == 4):
+            raise NotImplementedError(
+                "the MI355X MLP kernels are built for the reference's configured network only: "
+                "D=8, W=256, input_ch=63 (multires=10), input_ch_views=27 (multires_views=4), "
+                f"skips=[4], use_viewdirs=True; got D={D} W={W} input_ch={input_ch} "
+                f"input_ch_views={input_ch_views} skips={list(skips)} use_viewdirs={use_viewdirs}")
+        self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
+        self.skips, self.use_viewdirs = tuple(skips), use_viewdirs
+        dev = ops._dev() if device is None else torch.device(device)
+        self.device = dev
+        self.shapes = []
+        k = input_ch
+        for i in range(D):
+            self.shapes.append((k, W))
+            k = W + input_ch if i in skips else W
+        self.shapes += [(k, 256), (256 + input_ch_views, W // 2), (W // 2, 3), (k, 1)]
+        self.params = []
+        for (fi, fo) in self.shapes:  # Keras Dense defaults: glorot-uniform kernel, zero bias (:83)
+            lim = float(np.sqrt(6. / (fi + fo)))
+            w = (torch.rand((fi, fo), dtype=torch.float32, device=dev, generator=generator) * 2 - 1) * lim
+            self.params.append(w.requires_grad_(True))
+            self.params.append(torch.zeros((fo,), dtype=torch.float32, device=dev, requires_grad=True))
+        self._packed = torch.empty((ops.packed_bytes(),), dtype=torch.uint8, device=dev)
+        self._packed_version = None
+
+    # Keras-like surface
+    @property
+    def trainable_variables(self):
+        return list(self.params)
+
+    def get_weights(self):
+        return [p.detach().cpu().numpy() for p in self.params]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(self.params):
+            raise ValueError(f"set_weights: expected {len(self.params)} arrays, got {len(weights)}")
+        with torch.no_grad():
+            for p, w in zip(self.params, weights):
+                w = torch.as_tensor(np.asarray(w), dtype=torch.float32)
+                if tuple(w.shape) != tuple(p.shape):
+                    raise ValueError(f"set_weights: shape {tuple(w.shape)} does not match {tuple(p.shape)}")
+                p.copy_(w)
+        self._packed_version = None
+
+    def count_params(self):
+        return sum(p.numel() for p in self.params)
+
+    def packed(self):
+        """The fp16 fragment stream for the current parameter values (re-packed when they change)."""
+        ver = tuple(p._version for p in self.params)
+        if ver != self._packed_version:
+            with torch.no_grad():
+                ops.mlp_pack([p.detach() for p in self.params], self._packed)
+            self._packed_version = ver
+        return self._packed
+
+    def mark_dirty(self):
+        self._packed_version = None
+
+
+def init_nerf_model(D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4],
+                    use_viewdirs=False, device=None, generator=None):
+    """run_nerf_helpers.py:80-117."""
+    return NerfModel(int(D), int(W), int(input_ch), int(input_ch_views), int(output_ch), list(skips),
+                     bool(use_viewdirs), device=device, generator=generator)
+
+
+# ---- rays (run_nerf_helpers.py:122-180) --------------------------------------------------------
+def get_rays(H, W, focal, c2w):
+    """run_nerf_helpers.py:122-129 -> rays_o, rays_d [H,W,3] on the GPU."""
+    return ops.get_rays(H, W, focal, c2w)
+
+
+def get_rays_np(H, W, focal, c2w):
+    """run_nerf_helpers.py:135-142 -> NumPy arrays (computed on the GPU, copied back)."""
+    o, d = ops.get_rays(H, W, focal, c2w)
+    return o.cpu().numpy(), d.cpu().numpy()
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """run_nerf_helpers.py:145-180."""
+    return ops.ndc_rays(H, W, focal, near, rays_o, rays_d)
+
+
+# ---- hierarchical sampling (run_nerf_helpers.py:185-213) ---------------------------------------
+def sample_pdf(bins, weights, N_samples, det=False, u=None):
+    """run_nerf_helpers.py:185-213.  `u` lets a caller supply the uniforms the reference draws
+    with tf.random.uniform (:198)."""
+    return ops.sample_pdf(bins, weights, N_samples, det=det, u=u)
+
+
+def batchify(fn, chunk):
+    """run_nerf_helpers.py:216-223."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
