@@ -1,0 +1,169 @@
+"""Headline benchmark: rays/s of the per-ray render core at 64 coarse + 128 fine samples per ray.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole hot path (ray-batch assembly, depths, fused encoding+MLP coarse,
+compositing, resampling+merge, MLP fine, compositing) over a synthetic batch of 1,048,576 rays per
+GPU that is resident in HBM before the clock starts.  With N > 1 every rank renders its own batch
+(rays are independent: weak scaling, no collective on the data path) and the ranks all-gather the
+rendered maps (rgb, disp, acc: 20 B/ray) at the end of the step, as a sharded image render would.
+Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (the fused MLP) from HIP events
+recorded around every one of its launches inside the timed steps; `cpu_baseline` times the
+unfused torch-CPU restatement of the reference's TF op graph (oracle/torch_restatement.py) on a
+bounded sample of the same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_POINT = 2 * 593408          # one network, use_viewdirs (run_nerf_helpers.py:95-112)
+MFMA_PEAK_TFLOPS = 2500.0            # dense fp16/bf16 MFMA, MI355X
+N_RAYS = 1024 * 1024
+N_SAMPLES, N_IMPORTANCE = 64, 128
+
+
+def synthetic_batch(n, seed, device):
+    """Origins on a radius-4 sphere, directions toward uniform targets in [-1,1]^3, not normalised."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    o = torch.randn((n, 3), generator=g)
+    o = 4. * o / o.norm(dim=-1, keepdim=True)
+    tgt = torch.rand((n, 3), generator=g) * 2 - 1
+    d = (tgt - o) * (0.5 + torch.rand((n, 1), generator=g))
+    return o.to(device), d.to(device)
+
+
+def make_args():
+    return argparse.Namespace(
+        multires=10, multires_views=4, i_embed=0, use_viewdirs=True, netdepth=8, netwidth=256,
+        netdepth_fine=8, netwidth_fine=256, N_importance=N_IMPORTANCE, N_samples=N_SAMPLES,
+        netchunk=1024 * 64, perturb=0., raw_noise_std=0., white_bkgd=True, lindisp=False,
+        dataset_type='blender', no_ndc=False, basedir='/tmp/nerf_amd_bench', expname='bench',
+        ft_path=None, no_reload=True)
+
+
+def cpu_baseline(n_rays, seed=0):
+    """rays/s of the op-for-op torch-CPU restatement (fp32, chunk=32768, netchunk=65536)."""
+    from oracle import torch_restatement as trs
+    from oracle import nerf_oracle as orc
+    rng = np.random.default_rng(seed)
+    ws_c = [torch.as_tensor(w) for w in orc.init_nerf_weights(rng)]
+    ws_f = [torch.as_tensor(w) for w in orc.init_nerf_weights(rng)]
+    o, d = synthetic_batch(n_rays, seed, "cpu")
+    vd = d / d.norm(dim=-1, keepdim=True)
+    rb = torch.cat([o, d, torch.full((n_rays, 1), 2.), torch.full((n_rays, 1), 6.), vd], -1)
+    with torch.no_grad():
+        trs.render_flat(rb[:256], ws_c, ws_f, white_bkgd=True)  # warm the thread pool
+        t0 = time.perf_counter()
+        trs.render_flat(rb, ws_c, ws_f, chunk=1024 * 32, white_bkgd=True, netchunk=1024 * 64)
+        dt = time.perf_counter() - t0
+    return n_rays / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rays", type=int, default=N_RAYS, help="rays per GPU per step")
+    ap.add_argument("--chunk", type=int, default=1024 * 128, help="rays per render_rays call")
+    ap.add_argument("--cpu-rays", type=int, default=16384, help="sample size of the CPU baseline (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from nerf_amd import ops
+    from nerf_amd.run_nerf import create_nerf, render
+
+    torch.manual_seed(0)  # identical replicas of both networks on every rank
+    kw_train, kw_test, _, _, models = create_nerf(make_args())
+    o, d = synthetic_batch(a.rays, 1000 + rank, dev)
+    gathered = None
+    if world > 1:
+        gathered = [torch.empty((a.rays, 5), dtype=torch.float32, device=dev) for _ in range(world)]
+
+    def step():
+        rgb, disp, acc, _ = render(1, 1, 1., chunk=a.chunk, rays=(o, d), near=2., far=6., **kw_test)
+        if world > 1:
+            dist.all_gather(gathered, torch.cat([rgb, disp[:, None], acc[:, None]], -1))
+        return rgb
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    ops.MLP_TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rgb = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timing, ops.MLP_TIMING = ops.MLP_TIMING, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(rgb).all()), "render produced non-finite colours"
+
+    mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
+    mlp_points = sum(p for _, _, p in timing)
+    achieved = mlp_points * FLOP_PER_POINT / (mlp_ms * 1e-3) / 1e12
+    rays_per_s = world * a.rays * a.steps / dt
+
+    if rank == 0:
+        cpu = None
+        if a.cpu_rays > 0:
+            v, secs = cpu_baseline(a.cpu_rays)
+            cpu = {"value": round(v, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"{a.cpu_rays} rays of the same synthetic batch, 64+128 samples, chunk=32768, "
+                             f"netchunk=65536, fp32 torch-CPU restatement of the TF1.15 op graph, {secs:.1f} s"}
+        out = {
+            "metric": "render rays/sec (64+128 samples/ray)",
+            "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 (MFMA inputs; f32 accumulate, f32 compositing/sampling)",
+            "data": "synthetic",
+            "config": {"workload": f"render of a synthetic {a.rays}-ray batch per GPU, {N_SAMPLES} coarse + "
+                                   f"{N_IMPORTANCE} fine samples, fused MLP fwd + raw2outputs + sample_pdf",
+                       "rays_per_gpu": a.rays, "chunk": a.chunk, "networks": "2 x (D=8, W=256, skip 4, view head), random init",
+                       "parallelism": f"ray-sharded x{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "mlp_fwd_kernel", "launches": len(timing),
+                         "avg_launch_ms": round(mlp_ms / max(1, len(timing)), 4),
+                         "flop_per_point": FLOP_PER_POINT, "points_per_launch": mlp_points // max(1, len(timing)),
+                         "mlp_share_of_step": round(mlp_ms * 1e-3 / dt, 4)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,20 @@ def sample_z(rays, S, lindisp=False, perturb_u=None):
     return z
 
 
+# When a list, every MLP launch appends (start_event, end_event, points) -- bench.py's roofline leg.
+MLP_TIMING = None
+
+
+def _timed_mlp(points, launch):
+    if MLP_TIMING is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    MLP_TIMING.append((e0, e1, points))
+
+
 def packed_bytes():
     return int(nv.lib().nerf_mlp_packed_bytes())
 
@@ -123,8 +137,9 @@ def mlp_forward_rays(packed, rays, z):
         raise ValueError("mlp_forward_rays: rays and z disagree on the ray count")
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
     with torch.cuda.device(rays.device):
-        nv.check(nv.lib().nerf_mlp_forward_rays(nv.ptr(packed), nv.ptr(rays), width, nv.ptr(z), n, S,
-                                                nv.ptr(raw), nv.stream()), "nerf_mlp_forward_rays")
+        _timed_mlp(n * S, lambda: nv.check(
+            nv.lib().nerf_mlp_forward_rays(nv.ptr(packed), nv.ptr(rays), width, nv.ptr(z), n, S,
+                                           nv.ptr(raw), nv.stream()), "nerf_mlp_forward_rays"))
     return raw
 
 
@@ -135,8 +150,9 @@ def mlp_forward_pts(packed, pts, viewdirs):
         raise ValueError("mlp_forward_pts: need pts [N,S,3] and viewdirs [N,3]")
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):
-        nv.check(nv.lib().nerf_mlp_forward_pts(nv.ptr(packed), nv.ptr(pts), nv.ptr(viewdirs), n, S,
-                                               nv.ptr(raw), nv.stream()), "nerf_mlp_forward_pts")
+        _timed_mlp(n * S, lambda: nv.check(
+            nv.lib().nerf_mlp_forward_pts(nv.ptr(packed), nv.ptr(pts), nv.ptr(viewdirs), n, S,
+                                          nv.ptr(raw), nv.stream()), "nerf_mlp_forward_pts"))
     return raw
 
 
