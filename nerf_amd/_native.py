@@ -84,5 +84,10 @@ def f32(t, device=None):
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(t)
     if device is None:
-        device = t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        if t.is_cuda:
+            device = t.device
+        elif not torch.cuda.is_available():
+            raise NerfHipError("no GPU visible: nerf_amd runs on MI355X only (there is no CPU path)")
+        else:
+            device = torch.device("cuda", torch.cuda.current_device())
     return t.to(device=device, dtype=torch.float32).contiguous()

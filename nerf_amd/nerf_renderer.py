@@ -3,7 +3,7 @@ source is not in the reference tree): run_network, raw2outputs, render_rays.
 
 Semantics follow the call sites in run_nerf.py (:20, :209-214, :216-238, :775, :796-823), the
 in-tree simplified twin (tiny_nerf.ipynb, render_rays cell) and sample_pdf's shape contract
-(run_nerf_helpers.py:185-213); see oracle/nerf_oracle.py for the evidence per line.  Every stage is
+(run_nerf_helpers.py:185-213).  Every stage is
 one HIP kernel launch on the current stream: depths, fused encoding+MLP, compositing,
 resampling+merge, fused encoding+MLP, compositing.
 """

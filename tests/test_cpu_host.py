@@ -1,0 +1,182 @@
+"""CPU tests: the C-ABI library loads and exports every symbol the header declares (no compute
+call), host-side logic (checkpoint format, PNG writer, error behaviour) and the multi-process
+ray-sharding path under gloo with world_size 2."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(nerf_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from nerf_amd import _native
+    lib = _native.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/nerf_hip.h but not exported"
+        assert name in _native.SIGNATURES, f"{name} has no ctypes signature in nerf_amd/_native.py"
+    assert sorted(_native.SIGNATURES) == declared
+    assert lib.nerf_abi_version() == 1
+    assert lib.nerf_mlp_packed_bytes() == 74 * 16384 + 10 * 1024
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from nerf_amd import _native
+    lib = _native.lib()
+    # null pointers / bad sizes are rejected before any HIP call
+    assert lib.nerf_sample_z(4, 0, None, 11, 0, None, None, None) == -1
+    assert b"nerf_sample_z" in lib.nerf_last_error()
+    assert lib.nerf_mlp_forward_rays(None, None, 11, None, 1, 64, None, None) == -1
+    assert lib.nerf_build_ray_batch(1, None, None, None, 0, 1, 1, 1.0, None, None, 0.0, 1.0, None, 9, None) == -1
+    with pytest.raises(_native.NerfHipError):
+        _native.check(-1, "probe")
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must fail loudly, not compute on the host."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nerf_amd import _native, ops
+    with pytest.raises(_native.NerfHipError):
+        ops.get_rays(4, 4, 2.0, np.eye(4)[:3])
+    with pytest.raises(_native.NerfHipError):
+        ops.sample_z(torch.zeros((4, 11)), 8)
+
+
+def test_product_code_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "nerf_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, f"{f} mentions the oracle"
+
+
+def test_unsupported_network_shapes_raise():
+    from nerf_amd.run_nerf_helpers import NerfModel
+    with pytest.raises(NotImplementedError):
+        NerfModel(8, 128, 63, 27, 4, [4], True, device="cpu")
+    with pytest.raises(NotImplementedError):
+        NerfModel(8, 256, 63, 0, 4, [4], False, device="cpu")
+
+
+def test_checkpoint_roundtrip_and_safe_loader(tmp_path):
+    from nerf_amd import checkpoint
+
+    class Net:
+        def __init__(self, ws):
+            self.ws = ws
+
+        def get_weights(self):
+            return self.ws
+
+    rng = np.random.default_rng(0)
+    ws = [rng.normal(size=s).astype(np.float32) for s in [(63, 256), (256,), (319, 256), (256, 1), (1,)]]
+    path = checkpoint.save_weights(Net(ws), 'model', 200000, str(tmp_path), 'exp')
+    assert path.endswith('model_200000.npy')
+    assert int(path[-10:-4]) + 1 == 200001                        # run_nerf.py:254
+    assert '{}_fine_{}'.format(path[:-11], path[-10:]).endswith('model_fine_200000.npy')  # :258
+    back = checkpoint.load_weights(path)
+    assert len(back) == len(ws)
+    for a, b in zip(back, ws):
+        np.testing.assert_array_equal(a, b)
+    # the same file as the reference reads it
+    ref = np.load(path, allow_pickle=True)
+    assert len(ref) == len(ws) and ref[2].shape == (319, 256)
+    # a pickle that names anything but NumPy array constructors is refused
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    bad = np.empty((1,), dtype=object)
+    bad[0] = Evil()
+    p2 = str(tmp_path / "evil.npy")
+    np.save(p2, bad, allow_pickle=True)
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoint.load_weights(p2)
+
+
+def test_png_writer_roundtrip(tmp_path):
+    from nerf_amd.imageio_lite import imread, imwrite
+    from nerf_amd.run_nerf_helpers import to8b
+    img = to8b(np.random.default_rng(0).uniform(-0.2, 1.2, size=(7, 5, 3)))
+    assert img.dtype == np.uint8 and img.min() == 0 and img.max() == 255
+    p = str(tmp_path / "x.png")
+    imwrite(p, img)
+    np.testing.assert_array_equal(imread(p), img)
+    assert open(p, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+
+
+def test_shard_bounds_cover_all_rays():
+    from nerf_amd.parallel import shard_bounds
+    for n in [0, 1, 7, 8, 640000, 762048]:
+        for w in [1, 2, 3, 8]:
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            lens = [hi - lo for lo, hi in spans]
+            assert max(lens) - min(lens) <= 1
+
+
+def _worker(rank, world_size, port, tmp):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from nerf_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
+    try:
+        n = 1001  # odd: shards of 501 and 500 rays
+        g = torch.Generator().manual_seed(0)
+        rays = torch.rand((n, 11), generator=g)
+
+        def fake_render(r):  # deterministic per-ray function standing in for render_rays
+            return {'rgb_map': r[:, 0:3] * 2 + 1, 'disp_map': r[:, 6] * 3, 'acc_map': r[:, 7], 'depth_map': r[:, 8]}
+        out = parallel.render_sharded(fake_render, rays)
+        full = fake_render(rays)
+        for k in full:
+            assert out[k].shape == full[k].shape, k
+            assert torch.equal(out[k], full[k]), k
+        # data-parallel gradient: each rank's loss is divided by the GLOBAL ray count, SUM all-reduce
+        w = torch.nn.Parameter(torch.ones(11, 3))
+        b = torch.nn.Parameter(torch.zeros(3))
+        target = torch.rand((n, 3), generator=g)
+        mine = parallel.shard_rays(rays)
+        lo, hi = parallel.shard_bounds(n, rank, world_size)
+        loss = ((mine @ w + b - target[lo:hi]) ** 2).sum() / (n * 3)
+        gw, gb = torch.autograd.grad(loss, [w, b])
+        bucket = parallel.GradBucket([w, b])
+        bucket.views[0].copy_(gw)
+        bucket.views[1].copy_(gb)
+        bucket.allreduce_()
+        w2 = torch.nn.Parameter(torch.ones(11, 3))
+        b2 = torch.nn.Parameter(torch.zeros(3))
+        loss_full = ((rays @ w2 + b2 - target) ** 2).mean()
+        fw, fb = torch.autograd.grad(loss_full, [w2, b2])
+        assert torch.allclose(bucket.views[0], fw, atol=1e-6)
+        assert torch.allclose(bucket.views[1], fb, atol=1e-6)
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ray_sharding_two_ranks_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")

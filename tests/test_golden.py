@@ -1,0 +1,85 @@
+"""The committed golden vectors (tests/golden/render_core_v1.npz, written by make_golden.py from the
+fp64 oracle): the oracle must still reproduce them (CPU), and the HIP path must match them (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as orc
+from tests.util import trained_like_weights
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "render_core_v1.npz"))
+
+
+def _weights():
+    wc = trained_like_weights(np.random.default_rng(int(G['weights_seed'][0])))
+    wf = trained_like_weights(np.random.default_rng(int(G['weights_seed'][1])))
+    chk = [float(sum(np.sum(w.astype(np.float64)) for w in ws)) for ws in (wc, wf)]
+    np.testing.assert_allclose(chk, G['weights_checksum'], rtol=1e-12)
+    return wc, wf
+
+
+def test_oracle_reproduces_golden():
+    wc, wf = _weights()
+    H, W, focal = int(G['hwf'][0]), int(G['hwf'][1]), float(G['hwf'][2])
+    ro, rd = orc.get_rays(H, W, focal, G['c2w'], np.float32)
+    np.testing.assert_array_equal(ro, G['get_rays_o'])
+    np.testing.assert_array_equal(rd, G['get_rays_d'])
+    no, nd = orc.ndc_rays(H, W, focal, 1., ro, rd, np.float64)
+    np.testing.assert_allclose(no, G['ndc_o'], atol=1e-12)
+    np.testing.assert_allclose(orc.embed(G['embed_x'], 10), G['embed_10'], atol=1e-12)
+    np.testing.assert_allclose(orc.run_network(G['mlp_pts'], G['mlp_viewdirs'], wc), G['mlp_raw'], atol=1e-10)
+    out = orc.raw2outputs(G['comp_raw'], G['comp_z'], G['comp_d'], 0., True, dtype=np.float64)
+    np.testing.assert_allclose(out[0], G['comp_rgb_white1'], atol=1e-12)
+    np.testing.assert_allclose(orc.sample_pdf(G['pdf_bins'], G['pdf_weights'], 128, det=False, u=G['pdf_u'],
+                                              dtype=np.float64), G['pdf_samples_rand'], atol=1e-12)
+    r = orc.render_rays(G['rays'], wc, 64, N_importance=128, weights_fine=wf, white_bkgd=True, dtype=np.float64)
+    np.testing.assert_allclose(r['rgb_map'], G['e2e_white1_rgb_map'], atol=1e-10)
+    np.testing.assert_allclose(r['z_vals'], G['e2e_white1_z_vals'], atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_golden(gpu):
+    from nerf_amd import ops
+    from nerf_amd.run_nerf_helpers import get_rays, init_nerf_model, ndc_rays, sample_pdf
+    from nerf_amd.nerf_renderer import render_rays
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=gpu)
+    wc, wf = _weights()
+    H, W, focal = int(G['hwf'][0]), int(G['hwf'][1]), float(G['hwf'][2])
+    o, d = get_rays(H, W, focal, torch.as_tensor(G['c2w']))
+    np.testing.assert_array_equal(o.cpu().numpy(), G['get_rays_o'])
+    np.testing.assert_array_equal(d.cpu().numpy(), G['get_rays_d'])
+    no, nd = ndc_rays(H, W, focal, 1., o, d)
+    np.testing.assert_allclose(no.cpu().numpy(), G['ndc_o'], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(nd.cpu().numpy(), G['ndc_d'], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(ops.embed(t(G['embed_x']), 10).cpu().numpy(), G['embed_10'], atol=2e-6)
+    np.testing.assert_allclose(ops.embed(t(G['embed_x']), 4).cpu().numpy(), G['embed_4'], atol=2e-6)
+    mc, mf = [init_nerf_model(8, 256, 63, 27, 4, [4], True, device=gpu) for _ in range(2)]
+    mc.set_weights(wc)
+    mf.set_weights(wf)
+    raw = ops.mlp_forward_pts(mc.packed(), t(G['mlp_pts']), t(G['mlp_viewdirs'])).cpu().numpy().astype(np.float64)
+    sig = lambda v: 1. / (1. + np.exp(-v))
+    assert np.max(np.abs(sig(raw[..., :3]) - sig(G['mlp_raw'][..., :3]))) < 2e-3
+    assert np.max(np.abs(raw[..., 3] - G['mlp_raw'][..., 3])) < 4e-3 * max(1., np.max(np.abs(G['mlp_raw'][..., 3])))
+    for white in (0, 1):
+        out = ops.composite_fwd(t(G['comp_raw']), t(G['comp_z']), t(G['comp_d']), 3, bool(white))
+        for name, v in zip(['rgb', 'disp', 'acc', 'weights', 'depth'], out):
+            ref = G[f'comp_{name}_white{white}']
+            np.testing.assert_allclose(v.cpu().numpy(), ref, atol=1e-5 * max(1., np.max(np.abs(ref))), rtol=2e-5)
+    s = sample_pdf(t(G['pdf_bins']), t(G['pdf_weights']), 128, det=True).cpu().numpy()
+    np.testing.assert_allclose(s, G['pdf_samples_det'], atol=3e-5)
+    s = sample_pdf(t(G['pdf_bins']), t(G['pdf_weights']), 128, det=False, u=t(G['pdf_u'])).cpu().numpy()
+    np.testing.assert_allclose(s, G['pdf_samples_rand'], atol=3e-5)
+    rays = t(G['rays'])
+    np.testing.assert_allclose(ops.sample_z(rays, 64).cpu().numpy(), G['z_lin'], atol=1e-5)
+    np.testing.assert_allclose(ops.sample_z(rays, 64, True).cpu().numpy(), G['z_lindisp'], atol=1e-5)
+    np.testing.assert_allclose(ops.sample_z(rays, 64, False, t(G['perturb_u'])).cpu().numpy(), G['z_perturb'], atol=1e-5)
+    q = lambda *a: None
+    q.nerf_amd_fused = True
+    for white in (0, 1):
+        r = render_rays(rays, mc, q, 64, N_importance=128, network_fine=mf, white_bkgd=bool(white), retraw=True)
+        ok = np.abs(G['e2e_white1_raw_last_sigma']) > 5e-3  # last-sample knife edge (sign of sigma)
+        for k in ['rgb_map', 'acc_map', 'rgb0', 'acc0']:
+            err = np.abs(r[k].cpu().numpy() - G[f'e2e_white{white}_{k}'])[ok]
+            assert np.quantile(err, 0.99) < 2e-3 and err.max() < 2e-2, (k, err.max())
