@@ -127,6 +127,24 @@ int nerf_resample_merge(const float* z_vals, const float* weights, int64_t n, in
                         int det, const float* u, float* z_out, float* z_samples, float* z_std,
                         nerf_stream_t stream);
 
+/* ---- training: backward of the path (run_nerf.py:770-826, tf.GradientTape over render()) ---- */
+
+/* Gradient of raw2outputs: d_raw [n,S,4] from the gradients of rgb_map [n,3], acc_map [n] and
+ * depth_map [n] (any of the three may be NULL = zero).  Same raw/z/rays_d/noise as the forward
+ * call.  No gradient flows to z or rays_d (upstream stops it at the resampled depths). */
+int nerf_composite_bwd(const float* raw, const float* z, const float* rays_d, int d_stride,
+                       int64_t n, int S, int white_bkgd, const float* noise, float noise_std,
+                       const float* g_rgb, const float* g_acc, const float* g_depth, float* d_raw,
+                       nerf_stream_t stream);
+
+/* Bytes of activation scratch nerf_mlp_forward_train needs for n_points query points. */
+size_t nerf_mlp_act_bytes(int64_t n_points);
+
+/* nerf_mlp_forward_rays that also saves every layer's fp16 activations into `act`
+ * (nerf_mlp_act_bytes(n_rays*S) bytes) for nerf_mlp_backward. */
+int nerf_mlp_forward_train(const void* packed, const float* rays, int width, const float* z,
+                           int64_t n_rays, int S, float* raw, void* act, nerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

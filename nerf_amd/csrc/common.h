@@ -73,6 +73,28 @@ __device__ __forceinline__ float wave_shr1(float first, float v) {
     return dpp_or<0x138, 0xf>(first, v);  // wave_shr:1
 }
 
+// Lane i gets lane i+1's value; lane 63 gets `last`.
+__device__ __forceinline__ float wave_shl1(float last, float v) {
+    return dpp_or<0x130, 0xf>(last, v);  // wave_shl:1
+}
+
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Inclusive suffix sum over the wave's 64 lanes (lane i gets v_i + ... + v_63), summing only the
+// later lanes (no total-minus-prefix cancellation).
+__device__ __forceinline__ float wave_rscan_add(float v) {
+    v += dpp_or<0x101, 0xf>(0.0f, v);  // row_shl:1
+    v += dpp_or<0x102, 0xf>(0.0f, v);  // row_shl:2
+    v += dpp_or<0x104, 0xf>(0.0f, v);  // row_shl:4
+    v += dpp_or<0x108, 0xf>(0.0f, v);  // row_shl:8
+    const float t1 = read_lane(v, 16), t2 = read_lane(v, 32), t3 = read_lane(v, 48);
+    const int row = (threadIdx.x & 63) >> 4;
+    const float add = (row == 0) ? (t1 + t2) + t3 : (row == 1) ? t2 + t3 : (row == 2) ? t3 : 0.0f;
+    return v + add;
+}
+
 __device__ __forceinline__ float lane63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }

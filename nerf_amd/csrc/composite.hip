@@ -65,9 +65,109 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     }
 }
 
+// Backward of the compositing: d raw [n,S,4] from the gradients of rgb_map / acc_map / depth_map.
+// With c = sigmoid(raw_rgb), e = exp(-sigma*dist) (= 1 - alpha), t = e + 1e-10, T = exclusive
+// product of t, w = alpha*T and G_i = dL/dw_i = g_rgb.c_i + g_depth*z_i + g_acc (white background:
+// g_acc - sum(g_rgb)):
+//   dL/dalpha_i = G_i*T_i - (sum_{j>i} G_j*w_j)/t_i     (the division is TF's cumprod gradient)
+//   d raw_sigma = [sigma_pre > 0] * dist*e * dL/dalpha,    d raw_rgb = g_rgb * w * c*(1-c).
+// Two sweeps per ray: ascending 64-sample chunks to get each chunk's incoming transmittance,
+// then descending chunks with a suffix-sum scan carried from the far end.
+constexpr int kMaxChunks = 16;
+
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float4* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d,
+    int d_stride, int64_t n, int S, int white_bkgd, const float* __restrict__ noise,
+    float noise_std, const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
+    const float* __restrict__ g_depth, float4* __restrict__ d_raw) {
+    __shared__ float carry_in_all[4][kMaxChunks];
+    const int lane = threadIdx.x & 63;
+    float* carry_in = carry_in_all[threadIdx.x >> 6];
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int nch = (S + 63) >> 6;
+    for (int64_t ray = wave0; ray < n; ray += nwaves) {
+        const float dx = rays_d[ray * d_stride], dy = rays_d[ray * d_stride + 1],
+                    dz = rays_d[ray * d_stride + 2];
+        const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const int64_t row = ray * S;
+        const float gr = g_rgb ? g_rgb[ray * 3] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
+                    gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+        const float gd = g_depth ? g_depth[ray] : 0.f;
+        float ga = g_acc ? g_acc[ray] : 0.f;
+        if (white_bkgd) ga -= (gr + gg) + gb;
+
+        auto sample = [&](int s, float4& r, float& zz, float& dist, float& sig, float& e) {
+            const bool valid = s < S;
+            r = valid ? raw[row + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+            zz = valid ? z[row + s] : 0.f;
+            dist = ((s + 1 < S) ? z[row + s + 1] - zz : 1e10f) * norm;
+            sig = r.w;
+            if (noise) sig = sig + (valid ? noise[row + s] : 0.f) * noise_std;
+            e = valid ? __expf(-fmaxf(sig, 0.f) * dist) : 1.0f;  // 1 - alpha
+            return valid;
+        };
+
+        // sweep 1: transmittance entering each chunk
+        float carry = 1.0f;
+        for (int c = 0; c < nch; ++c) {
+            float4 r; float zz, dist, sig, e;
+            const bool valid = sample(c * 64 + lane, r, zz, dist, sig, e);
+            const float t = valid ? (1.0f - (1.0f - e)) + 1e-10f : 1.0f;
+            if (lane == 0) carry_in[c] = carry;
+            carry = carry * lane63(wave_scan_mul(t));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // sweep 2: far to near
+        float carry_r = 0.f;
+        for (int c = nch - 1; c >= 0; --c) {
+            const int s = c * 64 + lane;
+            float4 r; float zz, dist, sig, e;
+            const bool valid = sample(s, r, zz, dist, sig, e);
+            const float alpha = valid ? 1.0f - e : 0.f;
+            const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
+            const float T = carry_in[c] * wave_shr1(1.0f, wave_scan_mul(t));
+            const float w = alpha * T;
+            const float cr = sigmoidf(r.x), cg = sigmoidf(r.y), cb = sigmoidf(r.z);
+            const float G = ((gr * cr + gg * cg) + gb * cb) + (gd * zz + ga);
+            const float Gw = valid ? G * w : 0.f;
+            const float suf = wave_rscan_add(Gw);
+            const float R = wave_shl1(0.f, suf) + carry_r;   // sum over samples after this one
+            carry_r = carry_r + read_lane(suf, 0);
+            if (valid) {
+                const float dalpha = G * T - R / t;
+                const float dsig = (sig > 0.f) ? dist * (1.0f - alpha) * dalpha : 0.f;
+                d_raw[row + s] = make_float4(gr * w * cr * (1.0f - cr), gg * w * cg * (1.0f - cg),
+                                             gb * w * cb * (1.0f - cb), dsig);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 }  // namespace nerf
 
 using namespace nerf;
+
+NERF_API int nerf_composite_bwd(const float* raw, const float* z, const float* rays_d,
+                                int d_stride, int64_t n, int S, int white_bkgd,
+                                const float* noise, float noise_std, const float* g_rgb,
+                                const float* g_acc, const float* g_depth, float* d_raw,
+                                nerf_stream_t stream) {
+    NERF_REQUIRE(raw && z && rays_d && d_raw, "nerf_composite_bwd: null pointer");
+    NERF_REQUIRE(n >= 0 && S > 0 && d_stride >= 3, "nerf_composite_bwd: bad size");
+    NERF_REQUIRE(S <= 64 * kMaxChunks, "nerf_composite_bwd: at most %d samples per ray", 64 * kMaxChunks);
+    NERF_REQUIRE(((uintptr_t)raw & 15) == 0 && ((uintptr_t)d_raw & 15) == 0,
+                 "nerf_composite_bwd: raw and d_raw must be 16-byte aligned");
+    if (n == 0) return 0;
+    if (noise_std <= 0.f) noise = nullptr;
+    const int64_t want = (n + 3) / 4;
+    const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
+    composite_bwd_kernel<<<blocks, 256, 0, as_stream(stream)>>>(
+        (const float4*)raw, z, rays_d, d_stride, n, S, white_bkgd, noise, noise_std, g_rgb, g_acc,
+        g_depth, (float4*)d_raw);
+    return check_launch("nerf_composite_bwd");
+}
 
 NERF_API int nerf_composite_fwd(const float* raw, const float* z, const float* rays_d,
                                 int d_stride, int64_t n, int S, int white_bkgd,

@@ -1,0 +1,244 @@
+// Pieces shared by the fused MLP kernels (forward, training forward, backward chain): the
+// L2 -> LDS weight stream with its register prefetch pipeline, accumulator -> fragment
+// conversion, and the in-register positional encoding.  See mlp_layout.h for the data layout.
+#pragma once
+#include <type_traits>
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace nerf {
+using namespace layout;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define DEV __device__ __forceinline__
+
+constexpr int kPrefetch = 4;  // A fragments held in registers ahead of the MFMA (<= 8)
+constexpr int kPointsPerWave = 32;
+constexpr int kWavesPerBlock = 8;
+constexpr int kPointsPerBlock = kPointsPerWave * kWavesPerBlock;
+
+template <int I, int N, class F>
+DEV void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// s_waitcnt vmcnt(n) for a value that is a compile-time constant after unrolling (the switch
+// folds to one instruction); counts above the 6-bit field wait for 63, which is stricter.
+DEV void wait_vmcnt_n(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+        case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+        case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+        case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+        case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+        case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+        case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+        case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+        case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        default:
+            if (n < 0) __builtin_trap();
+            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            break;
+    }
+}
+
+// This wave's vector-memory operations (loads, direct-to-LDS loads, stores) counted at issue.
+// They retire in issue order, so "everything issued up to mark m has completed" is
+// s_waitcnt vmcnt(issued - m).  Every issue site must add exactly the instructions it emits (or
+// fewer: an undercount only makes a wait stricter).
+struct VmQueue {
+    int issued = 0;
+    DEV void wait_until(int mark) const { wait_vmcnt_n(issued - mark); }
+};
+
+DEV f32x16 mfma(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+DEV void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// The weight stream (NCHUNKS chunks of 16 KiB, RING LDS slots, DEPTH chunks in flight) and the
+// register pipeline of A fragments.  Fragments must be taken in stream order, F = 0, 1, 2, ...
+template <int NCHUNKS, int RING, int DEPTH>
+struct Stream {
+    static_assert(DEPTH <= RING - 2 && kPrefetch <= 8, "ring slack");
+    static constexpr int kRingBytes = RING * kChunkBytes;
+    VmQueue& vm;
+    const char* gsrc;   // this lane's source address inside chunk 0
+    char* lds;          // ring base
+    int wave_off;       // this wave's 2 KiB share of a chunk
+    int lane_off;       // lane * 16
+    int mark[RING];     // vm.issued right after each resident chunk's loads
+    half8 a[kPrefetch];
+
+    DEV Stream(VmQueue& q, const char* packed, char* lds_base, int wave, int lane)
+        : vm(q), gsrc(packed + wave * (2 * kFragBytes) + lane * 16), lds(lds_base),
+          wave_off(wave * (2 * kFragBytes)), lane_off(lane * 16) {}
+
+    template <int C>
+    DEV void issue() {
+        const char* g = gsrc + (size_t)C * kChunkBytes;
+        char* l = lds + (C % RING) * kChunkBytes + wave_off;
+        glds16(g, l);
+        glds16(g + kFragBytes, l + kFragBytes);
+        vm.issued += 2;
+        mark[C % RING] = vm.issued;
+    }
+
+    // Makes chunk C readable by every wave, then refills the ring slot of chunk C + DEPTH - RING.
+    template <int C>
+    DEV void sync() {
+        __builtin_amdgcn_sched_barrier(0);
+        vm.wait_until(mark[C % RING]);
+        asm volatile("s_barrier" ::: "memory");
+        if constexpr (C + DEPTH < NCHUNKS) issue<C + DEPTH>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    template <int F>
+    DEV half8 read() const {
+        constexpr int C = F / kFragsPerChunk;
+        const char* p = lds + (C % RING) * kChunkBytes + (F % kFragsPerChunk) * kFragBytes + lane_off;
+        return *(const half8*)p;
+    }
+
+    // Issues the first DEPTH chunks (call early, before any other work).
+    DEV void prologue() {
+        static_for<0, DEPTH>([&](auto c) { issue<decltype(c)::value>(); });
+    }
+
+    DEV void start() {
+        sync<0>();
+        static_for<0, kPrefetch>([&](auto i) { a[decltype(i)::value] = read<decltype(i)::value>(); });
+    }
+
+    // Returns fragment F and starts the read of fragment F + kPrefetch into its register slot.
+    template <int F>
+    DEV half8 take() {
+        const half8 cur = a[F % kPrefetch];
+        if constexpr ((F + 8) % kFragsPerChunk == 0 && (F + 8) / kFragsPerChunk < NCHUNKS)
+            sync<(F + 8) / kFragsPerChunk>();
+        if constexpr (F + kPrefetch < NCHUNKS * kFragsPerChunk) a[F % kPrefetch] = read<F + kPrefetch>();
+        return cur;
+    }
+};
+
+// The 32 values of tile T of an accumulator-ordered fp32 table in LDS (`table` already offset by
+// the lane half's 64 bytes): four broadcast reads.
+template <int T>
+DEV f32x16 load_bias_tile(const char* table) {
+    const f32x4* p = (const f32x4*)(table + T * 128);
+    const f32x4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    return f32x16{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3],
+                  q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
+}
+
+// Registers 8*S..8*S+7 of an accumulator tile -> one fp16 B fragment (round to nearest even),
+// clamped to the fp16 range; RELU folds the activation into the clamp (one v_med3_f32).
+template <int S, bool RELU>
+DEV half8 to_frag(const f32x16& v) {
+    half8 out;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const float lo = RELU ? 0.f : -65504.f;
+        f32x2 x = {__builtin_amdgcn_fmed3f(v[8 * S + j], lo, 65504.f),
+                   __builtin_amdgcn_fmed3f(v[8 * S + j + 1], lo, 65504.f)};
+        half2v p = __builtin_convertvector(x, half2v);
+        out[j] = p[0], out[j + 1] = p[1];
+    }
+    return out;
+}
+
+// x / (2 pi) reduced to about [-0.5, 0.5] revolutions with a two-term constant, so that the
+// hardware sin/cos (which take revolutions) see a small argument whatever the magnitude of x.
+DEV float to_revolutions(float x) {
+    const float kHi = 0x1.45f306p-3f, kLo = 0x1.b9391p-28f;  // hi + lo = 1/(2 pi)
+    const float k = rintf(x * kHi);
+    float f = __builtin_fmaf(x, kHi, -k);
+    return __builtin_fmaf(x, kLo, f);
+}
+
+DEV float double_revolutions(float f) {
+    const float g = f + f;  // exact
+    return g - rintf(g);    // exact
+}
+
+// Local encoding slots of this lane half: NF frequencies starting at 1 (h = 0) or
+// base_freq_h1 (h = 1); see pe_feature / view_feature in mlp_layout.h for the slot order.
+template <int NF, int NSLOT>
+DEV void encode(const float (&x)[3], int h, float base_freq_h1, float (&v)[NSLOT]) {
+    v[0] = h ? x[2] : x[0];
+    v[1] = h ? 0.f : x[1];
+    float f[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[c] = to_revolutions(h ? x[c] * base_freq_h1 : x[c]);
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[2 + 6 * a + c] = __builtin_amdgcn_sinf(f[c]);
+            v[2 + 6 * a + 3 + c] = __builtin_amdgcn_cosf(f[c]);
+            f[c] = double_revolutions(f[c]);
+        }
+    }
+#pragma unroll
+    for (int i = 2 + 6 * NF; i < NSLOT; ++i) v[i] = 0.f;
+}
+
+template <int NSLOT>
+DEV void pack_slots(const float (&v)[NSLOT], half8* out) {
+#pragma unroll
+    for (int s = 0; s < NSLOT / 8; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            f32x2 x = {v[8 * s + j], v[8 * s + j + 1]};
+            half2v p = __builtin_convertvector(x, half2v);
+            out[s][j] = p[0], out[s][j + 1] = p[1];
+        }
+    }
+}
+
+}  // namespace nerf

@@ -46,6 +46,36 @@ constexpr int kBiasBytes = 10 * kFragBytes;  // 78 tiles x 128 B = 9984 B, padde
 static_assert(BT_END * 128 <= kBiasBytes, "bias region");
 constexpr size_t kPackedBytes = kBiasOffset + kBiasBytes;
 
+// ---- training: activations saved by the forward pass, gradients saved by the backward chain ----
+// Both are stored as the 1 KiB B fragments the kernels already hold (lane = point within a
+// 32-point wave tile, 8 fp16 features per lane), [wave tile][block], so a wave writes or reads a
+// block as one coalesced 1 KiB transaction.
+constexpr int A_PE = 0;      //  4 blocks: point encoding (64 slots)
+constexpr int A_H0 = 4;      // 16 blocks per layer output h0..h7 (after ReLU): A_H0 + 16*l
+constexpr int A_BOTT = 132;  // 16 blocks: bottleneck (linear)
+constexpr int A_V = 148;     //  8 blocks: view layer output (after ReLU)
+constexpr int A_VPE = 156;   //  2 blocks: view-direction encoding (32 slots)
+constexpr int kActBlocks = 158;
+
+constexpr int G_DV = 0;      //  8 blocks: d(view layer pre-activation)
+constexpr int G_DBOTT = 8;   // 16 blocks: d(bottleneck)
+constexpr int G_DPRE0 = 24;  // 16 blocks per layer: d(pre-activation of layer l): G_DPRE0 + 16*l
+constexpr int G_DA = 152;    //  1 block: d(alpha) in feature slot 0
+constexpr int G_DC = 153;    //  1 block: d(rgb) in feature slots 0..2
+constexpr int kGradBlocks = 154;
+
+// ---- backward weight stream: d h_in = W . d y, A = W[in][out] with the out index permuted as
+// the incoming gradient fragments are ----
+constexpr int B_V = 0;       //  1 x 4   d rgb(16 slots)            -> d v (128)
+constexpr int B_BOTT = 4;    //  8 x 8   d v_pre(128)               -> d bottleneck (256)
+constexpr int B_H7 = 68;     // 17 x 8   [d bott(256) ; d alpha(16)] -> d h7
+constexpr int B_H6 = 204;    // 16 x 8   x7: d pre_{l+1} -> d h_l for l = 6..0 (layer 5: rows 63.. of its kernel)
+constexpr int B_END_USED = 1100;
+constexpr int B_END = 1104;  // padded to a chunk boundary
+constexpr int kBwdChunks = B_END / kFragsPerChunk;  // 69
+constexpr size_t kPackedBwdBytes = (size_t)kBwdChunks * kChunkBytes;
+static_assert(B_H6 + 7 * 128 == B_END_USED && B_END % kFragsPerChunk == 0, "backward stream");
+
 // Feature of the previous layer's output held by element j of lane half h in k-step k
 // (k-step k = accumulator tile k>>1, register group k&1).
 __host__ __device__ constexpr int acc_feature(int k, int h, int j) {

@@ -225,3 +225,34 @@ def resample_merge(z_vals, weights, N_importance, det=True, u=None, want_samples
                                               nv.ptr(z_out), nv.ptr(z_samples), nv.ptr(z_std),
                                               nv.stream()), "nerf_resample_merge")
     return z_out, z_samples, z_std
+
+
+def composite_bwd(raw, z, rays_d, d_stride, white_bkgd, noise, noise_std, g_rgb, g_acc=None, g_depth=None):
+    """d_raw [N,S,4] from the gradients of rgb_map / acc_map / depth_map (None = zero)."""
+    n, S = z.shape
+    d_raw = torch.empty((n, S, 4), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        nv.check(nv.lib().nerf_composite_bwd(nv.ptr(raw), nv.ptr(z), ctypes.c_void_p(rays_d.data_ptr()),
+                                             int(d_stride), n, S, int(bool(white_bkgd)), nv.ptr(noise),
+                                             float(noise_std), nv.ptr(g_rgb), nv.ptr(g_acc),
+                                             nv.ptr(g_depth), nv.ptr(d_raw), nv.stream()),
+                 "nerf_composite_bwd")
+    return d_raw
+
+
+def act_bytes(n_points):
+    return int(nv.lib().nerf_mlp_act_bytes(int(n_points)))
+
+
+def mlp_forward_train(packed, rays, z, act):
+    """mlp_forward_rays that also fills `act` (uint8 [act_bytes(N*S)]) for the backward pass."""
+    n, width = rays.shape
+    S = z.shape[1]
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=rays.device)
+    if act.numel() < act_bytes(n * S):
+        raise ValueError("mlp_forward_train: activation scratch too small")
+    with torch.cuda.device(rays.device):
+        _timed_mlp(n * S, lambda: nv.check(
+            nv.lib().nerf_mlp_forward_train(nv.ptr(packed), nv.ptr(rays), width, nv.ptr(z), n, S,
+                                            nv.ptr(raw), nv.ptr(act), nv.stream()), "nerf_mlp_forward_train"))
+    return raw
