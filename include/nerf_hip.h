@@ -145,6 +145,26 @@ size_t nerf_mlp_act_bytes(int64_t n_points);
 int nerf_mlp_forward_train(const void* packed, const float* rays, int width, const float* z,
                            int64_t n_rays, int S, float* raw, void* act, nerf_stream_t stream);
 
+/* Transposed fp16 weight stream for the backward chain (nerf_mlp_packed_bwd_bytes() bytes),
+ * from the same 24 parameter arrays as nerf_mlp_pack. */
+size_t nerf_mlp_packed_bwd_bytes(void);
+int nerf_mlp_pack_bwd(const float* const* params, void* packed_bwd, nerf_stream_t stream);
+
+/* Scratch sizes of nerf_mlp_backward: fp16 layer gradients for n_points, and the fp32
+ * partial-sum buffer (fixed size). */
+size_t nerf_mlp_grad_bytes(int64_t n_points);
+size_t nerf_mlp_partial_bytes(void);
+
+/* Gradient of the network parameters (tape.gradient(loss, grad_vars), run_nerf.py:825, restricted
+ * to one network): d_raw [n_points,4] -> grads: HOST array of 24 device pointers in get_weights()
+ * order, each shaped like its parameter.  `act` is what nerf_mlp_forward_train saved for the same
+ * points.  The chain runs in fp16 with fp32 accumulation; d_raw is multiplied by `gscale` first
+ * (choose it so that gscale*|d_raw| is around 1e-2..1e2) and the result divided by it.
+ * accumulate != 0 adds into grads instead of overwriting.  No gradient flows to rays or depths. */
+int nerf_mlp_backward(const void* packed_bwd, const void* act, const float* d_raw, int64_t n_points,
+                      float gscale, void* gbuf, void* partial, float* const* grads, int accumulate,
+                      nerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

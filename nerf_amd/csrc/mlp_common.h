@@ -82,10 +82,12 @@ DEV void wait_vmcnt_n(int n) {
     }
 }
 
-// This wave's vector-memory operations (loads, direct-to-LDS loads, stores) counted at issue.
-// They retire in issue order, so "everything issued up to mark m has completed" is
-// s_waitcnt vmcnt(issued - m).  Every issue site must add exactly the instructions it emits (or
-// fewer: an undercount only makes a wait stricter).
+// This wave's vector-memory LOADS (ordinary and direct-to-LDS) counted at issue.  Loads retire in
+// issue order among themselves, so "every load issued up to mark m has completed" is
+// s_waitcnt vmcnt(issued - m).  Stores share the hardware counter but may retire out of order
+// with respect to loads, so they are deliberately NOT counted: an uncounted pending store can
+// only make a wait stricter, whereas a counted store that retired early would let the wait
+// pass with the wanted load still in flight.  An issue site may also undercount (stricter).
 struct VmQueue {
     int issued = 0;
     DEV void wait_until(int mark) const { wait_vmcnt_n(issued - mark); }

@@ -1,0 +1,506 @@
+// Backward of the NeRF MLP (the tf.GradientTape of run_nerf.py:770-826 restricted to the network):
+// gradients of the 24 parameter arrays from d raw [M,4] and the activations the training forward
+// saved.  Three kernels:
+//
+//  1. mlp_bwd_chain_kernel -- d h_l = W_{l+1} . d pre_{l+1}, masked by h_l > 0, from the rgb/alpha
+//     heads down to layer 0.  Same structure as the forward kernel: transposed products with
+//     v_mfma_f32_32x32x16_f16, the gradient of a 32-point wave tile stays in registers, the
+//     (transposed-packed) weights stream L2 -> LDS once per workgroup.  ReLU masks come from the
+//     saved activations through a small per-wave LDS ring (direct-to-LDS loads, no barrier:
+//     a wave only reads what it loaded itself).  Every d pre_l is written out as fp16 fragments.
+//     Gradients are multiplied by `gscale` on entry so that they sit inside the fp16 range.
+//  2. mlp_dw_kernel -- per layer, dW^T[out][in] = sum over points of d pre[out][pt] * x[pt][in].
+//     The contraction runs over points, which the stored fragments keep on the lane, so every
+//     operand is rebuilt with the transposing LDS read (ds_read_b64_tr_b16).  One workgroup
+//     owns a (layer, point range) pair, keeps the whole dW^T of the layer in accumulators
+//     (wave w = output tile w) and adds it to a global fp32 buffer once at the end.  A constant
+//     "ones" input column yields the bias gradient from the same product.  HBM-bound:
+//     ~10.6 KB/point read for 1.19 MFLOP/point.
+//  3. mlp_grad_unpack_kernel -- accumulator-ordered partial sums -> the 24 arrays, times 1/gscale.
+#include "mlp_common.h"
+
+namespace nerf {
+
+// ---------------------------------------------------------------------------------------------
+// backward weight stream
+// ---------------------------------------------------------------------------------------------
+struct ParamPtrsB {
+    const float* p[24];
+};
+
+__global__ __launch_bounds__(64) void mlp_pack_bwd_kernel(ParamPtrsB pp, char* __restrict__ packed) {
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int F = blockIdx.x;
+    const float* Wm = nullptr;  // kernel [in, out]
+    int out_dim = 0, in = -1, in_rows = 0;
+    int outs[8];
+    for (int j = 0; j < 8; ++j) outs[j] = -1;
+    if (F < B_BOTT) {                       // d v = W_rgb . d rgb
+        Wm = pp.p[20], out_dim = 3, in_rows = 128, in = 32 * F + r;
+        for (int j = 0; j < 8; ++j) { const int f = acc_feature(0, h, j); outs[j] = f < 3 ? f : -1; }
+    } else if (F < B_H7) {                  // d bott = W_view[0:256] . d v_pre
+        const int q = F - B_BOTT, t = q / 8, k = q % 8;
+        Wm = pp.p[18], out_dim = 128, in_rows = 256, in = 32 * t + r;
+        for (int j = 0; j < 8; ++j) outs[j] = acc_feature(k, h, j);
+    } else if (F < B_H6) {                  // d h7 = W_bott . d bott + W_alpha . d alpha
+        const int q = F - B_H7, t = q / 17, k = q % 17;
+        in = 32 * t + r, in_rows = 256;
+        if (k < 16) {
+            Wm = pp.p[16], out_dim = 256;
+            for (int j = 0; j < 8; ++j) outs[j] = acc_feature(k, h, j);
+        } else {
+            Wm = pp.p[22], out_dim = 1;
+            for (int j = 0; j < 8; ++j) outs[j] = acc_feature(0, h, j) == 0 ? 0 : -1;
+        }
+    } else if (F < B_END_USED) {            // d h_l = W_{l+1} . d pre_{l+1}, l = 6..0
+        const int q = F - B_H6, step = q / 128, t = (q % 128) / 16, k = q % 16;
+        const int layer = 7 - step;         // the kernel used: layers 7, 6, 5, 4, 3, 2, 1
+        Wm = pp.p[2 * layer], out_dim = 256, in_rows = (layer == 5) ? 319 : 256;
+        in = 32 * t + r + (layer == 5 ? 63 : 0);
+        for (int j = 0; j < 8; ++j) outs[j] = acc_feature(k, h, j);
+    }
+    _Float16* dst = (_Float16*)(packed + (size_t)F * kFragBytes) + lane * 8;
+    for (int j = 0; j < 8; ++j) {
+        const float v = (Wm && in < in_rows && outs[j] >= 0) ? Wm[(size_t)in * out_dim + outs[j]] : 0.f;
+        dst[j] = (_Float16)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. gradient chain
+// ---------------------------------------------------------------------------------------------
+constexpr int kBwdRing = 7, kBwdDepth = 5;
+using BwdStream = Stream<kBwdChunks, kBwdRing, kBwdDepth>;
+constexpr int kMaskDepth = 3;                       // mask tiles in flight per wave
+constexpr int kMaskTiles = 4 + 8 * 8;               // v (4 tiles), h7 .. h0 (8 tiles each)
+constexpr int kMaskBytesPerWave = kMaskDepth * 2 * kFragBytes;
+constexpr int kBwdLds = BwdStream::kRingBytes + kWavesPerBlock * kMaskBytesPerWave;
+static_assert(kBwdLds <= 160 * 1024, "LDS budget");
+
+typedef short short8 __attribute__((ext_vector_type(8)));
+
+// Block of the saved activations that masks tile M of the chain.
+__host__ __device__ constexpr int mask_block(int M) {
+    return M < 4 ? A_V + 2 * M : A_H0 + 16 * (7 - (M - 4) / 8) + 2 * ((M - 4) % 8);
+}
+
+struct MaskPipe {
+    VmQueue& vm;
+    const char* gact;  // this lane's address in block 0 of its wave tile's activations
+    char* lds;         // this wave's slice
+    int lane_off;
+    int mark[kMaskDepth];
+
+    template <int M>
+    DEV void issue() {
+        const char* g = gact + mask_block(M) * kFragBytes;
+        char* l = lds + (M % kMaskDepth) * 2 * kFragBytes;
+        glds16(g, l);
+        glds16(g + kFragBytes, l + kFragBytes);
+        vm.issued += 2;
+        mark[M % kMaskDepth] = vm.issued;
+    }
+
+    // The two activation fragments of mask tile M; then refills its slot with tile M + depth.
+    template <int M>
+    DEV void get(half8& m0, half8& m1) {
+        vm.wait_until(mark[M % kMaskDepth]);
+        const char* l = lds + (M % kMaskDepth) * 2 * kFragBytes + lane_off;
+        m0 = *(const half8*)l;
+        m1 = *(const half8*)(l + kFragBytes);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the slot is refilled
+        if constexpr (M + kMaskDepth < kMaskTiles) issue<M + kMaskDepth>();
+    }
+};
+
+DEV half8 mask_by(half8 d, half8 act) {
+    const short8 keep = __builtin_bit_cast(short8, act) != (short8)0;  // -1 where the unit was active
+    return __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, d) & keep));
+}
+
+struct GradSink {
+    char* base;
+    template <int BLK>
+    DEV void put(VmQueue& vm, const half8& v) const {
+        *(half8*)(base + BLK * kFragBytes) = v;  // stores are not counted: see VmQueue
+        (void)vm;
+    }
+};
+
+struct ChainArgs {
+    const char* packed_bwd;
+    const char* act;
+    const float4* d_raw;  // [M]
+    char* gbuf;           // [wave tiles][kGradBlocks][1 KiB]
+    int64_t M;
+    float gscale;
+};
+
+template <int F0, int NT, int NK, int MASK0, int GBLK, class GetB>
+DEV void bwd_layer(BwdStream& st, MaskPipe& mp, const GradSink& sink, half8* out, GetB&& getB) {
+    static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        static_for<0, NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            acc = mfma(st.template take<F0 + t * NK + k>(), getB(kc), acc);
+        });
+        half8 d0 = to_frag<0, false>(acc), d1 = to_frag<1, false>(acc);
+        if constexpr (MASK0 >= 0) {
+            half8 m0, m1;
+            mp.template get<MASK0 + t>(m0, m1);
+            d0 = mask_by(d0, m0);
+            d1 = mask_by(d1, m1);
+        }
+        out[2 * t] = d0;
+        out[2 * t + 1] = d1;
+        sink.template put<GBLK + 2 * t>(st.vm, d0);
+        sink.template put<GBLK + 2 * t + 1>(st.vm, d1);
+    });
+}
+
+__global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[kBwdLds];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+    const int64_t wave_tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+
+    VmQueue vm;
+    BwdStream st(vm, a.packed_bwd, lds, wave, lane);
+    st.prologue();
+    MaskPipe mp{vm, a.act + (size_t)wave_tile * kActBlocks * kFragBytes + lane * 16,
+                lds + BwdStream::kRingBytes + wave * kMaskBytesPerWave, lane * 16, {}};
+    static_for<0, kMaskDepth>([&](auto m) { mp.template issue<decltype(m)::value>(); });
+    GradSink sink{a.gbuf + (size_t)wave_tile * kGradBlocks * kFragBytes + lane * 16};
+
+    const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + (lane & 31);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < a.M && h == 0) g = a.d_raw[p];
+    half8 dC = {0, 0, 0, 0, 0, 0, 0, 0}, dA = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const float lim = 65504.f;
+        dC[0] = (_Float16)__builtin_amdgcn_fmed3f(g.x * a.gscale, -lim, lim);
+        dC[1] = (_Float16)__builtin_amdgcn_fmed3f(g.y * a.gscale, -lim, lim);
+        dC[2] = (_Float16)__builtin_amdgcn_fmed3f(g.z * a.gscale, -lim, lim);
+        dA[0] = (_Float16)__builtin_amdgcn_fmed3f(g.w * a.gscale, -lim, lim);
+    }
+    sink.template put<G_DA>(vm, dA);
+    sink.template put<G_DC>(vm, dC);
+
+    half8 fa[16], fb[16];
+    auto from_a = [&](auto kc) { return fa[decltype(kc)::value]; };
+    auto from_b = [&](auto kc) { return fb[decltype(kc)::value]; };
+
+    st.start();
+    bwd_layer<B_V, 4, 1, 0, G_DV>(st, mp, sink, fa, [&](auto) { return dC; });              // d v_pre
+    bwd_layer<B_BOTT, 8, 8, -1, G_DBOTT>(st, mp, sink, fb, from_a);                          // d bott
+    bwd_layer<B_H7, 8, 17, 4, G_DPRE0 + 16 * 7>(st, mp, sink, fa, [&](auto kc) {             // d pre7
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < 16) return fb[k]; else return dA;
+    });
+    bwd_layer<B_H6 + 0 * 128, 8, 16, 12, G_DPRE0 + 16 * 6>(st, mp, sink, fb, from_a);        // d pre6
+    bwd_layer<B_H6 + 1 * 128, 8, 16, 20, G_DPRE0 + 16 * 5>(st, mp, sink, fa, from_b);        // d pre5
+    bwd_layer<B_H6 + 2 * 128, 8, 16, 28, G_DPRE0 + 16 * 4>(st, mp, sink, fb, from_a);        // d pre4
+    bwd_layer<B_H6 + 3 * 128, 8, 16, 36, G_DPRE0 + 16 * 3>(st, mp, sink, fa, from_b);        // d pre3
+    bwd_layer<B_H6 + 4 * 128, 8, 16, 44, G_DPRE0 + 16 * 2>(st, mp, sink, fb, from_a);        // d pre2
+    bwd_layer<B_H6 + 5 * 128, 8, 16, 52, G_DPRE0 + 16 * 1>(st, mp, sink, fa, from_b);        // d pre1
+    bwd_layer<B_H6 + 6 * 128, 8, 16, 60, G_DPRE0 + 16 * 0>(st, mp, sink, fb, from_a);        // d pre0
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. weight gradients
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxInTiles = 11;   // layer 5: 2 (encoding) + 8 (h4) + 1 (ones column for the bias)
+constexpr int kMaxXBlocks = 20, kMaxYBlocks = 16;
+constexpr int kDwStageBytes = (kMaxXBlocks + kMaxYBlocks) * kFragBytes;  // 36 KiB
+constexpr int kDwStages = 3;
+constexpr int kNumJobs = 12;
+
+struct DwJob {
+    int x0_blk, x0_k;    // first input segment: block in the activation buffer, k-steps
+    int x1_blk, x1_k;    // second input segment (0 k-steps if none)
+    int y_blk, y_k;      // gradient segment: block in the gradient buffer, k-steps (1 or even)
+    int n_in;            // input tiles including the trailing ones tile
+    int n_out;           // output tiles (<= 8): wave w owns output tile w
+    int tile0;           // first 32x32 tile of this job in the partial-sum buffer
+    int wg0, wgs;        // workgroups [wg0, wg0 + wgs) split the wave tiles of this job
+};
+
+struct DwArgs {
+    const char* act;
+    const char* gbuf;
+    float* gperm;        // [tiles][16 regs][64 lanes]
+    int64_t wave_tiles;
+    DwJob job[kNumJobs];
+};
+
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+// Operand fragment (A or B alike) of the 32 features of blocks (blk, blk+1) x the 16 points
+// 16*kp .. 16*kp+15 of a staged wave tile: lane (r = feature slot, hh) gets points 8*hh .. 8*hh+7.
+// `one_block`: the segment has a single k-step; the upper 16 feature slots read as zero.
+DEV half8 tr_operand(const char* stage, int blk, int kp, int lane, bool one_block) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int s = blk + (g & 1);
+    const int c = 16 * kp + 8 * (g >> 1) + q;
+    const char* base = stage + s * kFragBytes + (32 * (p >> 1) + c) * 16 + 8 * (p & 1);
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)base);
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + 4 * 16));
+    short8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (one_block && (g & 1)) v = (short8)0;
+    return __builtin_bit_cast(half8, v);
+}
+
+__global__ __launch_bounds__(512) void mlp_dw_kernel(DwArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[kDwStages * kDwStageBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // which job / slice this workgroup owns
+    int ji = 0;
+#pragma unroll
+    for (int j = 1; j < kNumJobs; ++j)
+        if ((int)blockIdx.x >= a.job[j].wg0) ji = j;
+    const DwJob jb = a.job[ji];
+    const int slice = blockIdx.x - jb.wg0;
+    const int64_t per = (a.wave_tiles + jb.wgs - 1) / jb.wgs;
+    const int64_t t_lo = slice * per, t_hi = (t_lo + per < a.wave_tiles) ? t_lo + per : a.wave_tiles;
+    const int xk = jb.x0_k + jb.x1_k, nblk = xk + jb.y_k;
+
+    // stage one wave tile: blocks are dealt round-robin to the 8 waves, 1 KiB per wave-load
+    auto stage_in = [&](int64_t wt, int buf) -> int {
+        char* dst = lds + buf * kDwStageBytes;
+        const char* ab = a.act + (size_t)wt * kActBlocks * kFragBytes + lane * 16;
+        const char* gb = a.gbuf + (size_t)wt * kGradBlocks * kFragBytes + lane * 16;
+        int mine = 0;
+        for (int b = wave; b < nblk; b += kWavesPerBlock) {
+            const char* src = (b < jb.x0_k) ? ab + (size_t)(jb.x0_blk + b) * kFragBytes
+                            : (b < xk)      ? ab + (size_t)(jb.x1_blk + b - jb.x0_k) * kFragBytes
+                                            : gb + (size_t)(jb.y_blk + b - xk) * kFragBytes;
+            glds16(src, dst + b * kFragBytes);
+            ++mine;
+        }
+        return mine;
+    };
+
+    f32x16 acc[kMaxInTiles];
+#pragma unroll
+    for (int i = 0; i < kMaxInTiles; ++i)
+        acc[i] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // constant operand of the ones column: input slot 0 is 1 for every point
+    half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((lane & 31) == 0) ones = half8{1, 1, 1, 1, 1, 1, 1, 1};
+
+    const int64_t ntile = t_hi - t_lo;
+    int inflight[kDwStages] = {0, 0, 0};   // loads this wave issued per staged tile
+    if (ntile > 0) inflight[0] = stage_in(t_lo, 0);
+    if (ntile > 1) inflight[1] = stage_in(t_lo + 1, 1);
+    for (int64_t it = 0; it < ntile; ++it) {
+        const int buf = (int)(it % kDwStages);
+        // everything but the next tile's loads has landed
+        wait_vmcnt_n((it + 1 < ntile) ? inflight[(it + 1) % kDwStages] : 0);
+        asm volatile("s_barrier" ::: "memory");
+        // the buffer read two iterations ago is free again (every wave passed the barrier above)
+        if (it + 2 < ntile) inflight[(it + 2) % kDwStages] = stage_in(t_lo + it + 2, (int)((it + 2) % kDwStages));
+        if (wave < jb.n_out) {
+            const char* stage = lds + buf * kDwStageBytes;
+            const bool y_one = jb.y_k == 1;
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const half8 ya = tr_operand(stage, xk + 2 * wave, kp, lane, y_one);
+                static_for<0, kMaxInTiles>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if (i < jb.n_in - 1) {
+                        const half8 xb = tr_operand(stage, 2 * i, kp, lane, false);
+                        acc[i] = mfma(ya, xb, acc[i]);
+                    } else if (i == jb.n_in - 1) {
+                        acc[i] = mfma(ya, ones, acc[i]);
+                    }
+                });
+            }
+        }
+    }
+    // add this workgroup's partial dW^T to the global buffer (256 contiguous bytes per register)
+    if (wave < jb.n_out && ntile > 0) {
+        static_for<0, kMaxInTiles>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (i < jb.n_in) {
+                float* dst = a.gperm + ((size_t)(jb.tile0 + wave * jb.n_in + i) * 16) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, acc[i][r]);
+            }
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. unpack
+// ---------------------------------------------------------------------------------------------
+struct GradPtrs {
+    float* g[24];
+};
+
+struct UnpackArgs {
+    const float* gperm;
+    GradPtrs out;
+    float inv_scale;
+    int accumulate;
+    int tile0[kNumJobs];
+    int n_in[kNumJobs];
+};
+
+// Slot (tile, row) of feature f of a 256- or 128-wide activation in fragment order.
+__device__ __forceinline__ void acc_slot(int f, int& tile, int& row) {
+    const int s = 2 * (f >> 5) + ((f >> 4) & 1), f16 = f & 15;
+    const int h = (f16 >> 2) & 1, j = ((f16 >> 3) << 2) | (f16 & 3);
+    tile = s >> 1, row = 16 * (s & 1) + 8 * h + j;
+}
+
+// Slot of feature f of an encoding (nfreq_per_half frequencies per lane half).
+__device__ __forceinline__ void enc_slot(int f, int nfreq_per_half, int& tile, int& row) {
+    int h, idx;
+    if (f == 0) h = 0, idx = 0;
+    else if (f == 1) h = 0, idx = 1;
+    else if (f == 2) h = 1, idx = 0;
+    else {
+        const int q = (f - 3) / 6, b = (f - 3) % 6;
+        h = q / nfreq_per_half;
+        idx = 2 + 6 * (q % nfreq_per_half) + b;
+    }
+    const int s = idx >> 3, j = idx & 7;
+    tile = s >> 1, row = 16 * (s & 1) + 8 * h + j;
+}
+
+// One thread per parameter scalar.  `pi` = parameter array (get_weights order), e = flat index.
+__global__ void mlp_grad_unpack_kernel(UnpackArgs a, int pi, int in_dim, int out_dim) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool is_bias = pi & 1;
+    const int count = is_bias ? out_dim : in_dim * out_dim;
+    if (e >= count) return;
+    const int layer = pi >> 1;  // 0..7 point layers, 8 bottleneck, 9 view, 10 rgb, 11 alpha
+    const int in = is_bias ? -1 : e / out_dim, out = is_bias ? e : e % out_dim;
+    // job of each layer: 0..7 -> jobs 0..7, bottleneck 8, alpha 9, view 10, rgb 11
+    const int job = layer <= 8 ? layer : (layer == 9 ? 10 : (layer == 10 ? 11 : 9));
+    int ot, orow, it, irow;
+    if (layer == 10 || layer == 11) ot = 0, orow = out;           // d rgb slots 0..2 / d alpha slot 0
+    else acc_slot(out, ot, orow);
+    const int n_in = a.n_in[job];
+    if (is_bias) it = n_in - 1, irow = 0;
+    else if (layer == 0) enc_slot(in, 5, it, irow);
+    else if (layer == 5) { if (in < 63) enc_slot(in, 5, it, irow); else { acc_slot(in - 63, it, irow); it += 2; } }
+    else if (layer == 9) { if (in < 256) acc_slot(in, it, irow); else { enc_slot(in - 256, 2, it, irow); it += 8; } }
+    else acc_slot(in, it, irow);
+    const int reg = (orow & 3) + 4 * (orow >> 3), lane = 32 * ((orow >> 2) & 1) + irow;
+    const float v = a.gperm[((size_t)(a.tile0[job] + ot * n_in + it) * 16 + reg) * 64 + lane] * a.inv_scale;
+    float* dst = a.out.g[pi] + e;
+    *dst = a.accumulate ? *dst + v : v;
+}
+
+// the twelve (layer input, layer gradient) products
+static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs) {
+    auto set = [&](int j, int x0b, int x0k, int x1b, int x1k, int yb, int yk, int n_out) {
+        jb[j].x0_blk = x0b, jb[j].x0_k = x0k, jb[j].x1_blk = x1b, jb[j].x1_k = x1k;
+        jb[j].y_blk = yb, jb[j].y_k = yk, jb[j].n_in = (x0k + x1k) / 2 + 1, jb[j].n_out = n_out;
+    };
+    set(0, A_PE, 4, 0, 0, G_DPRE0, 16, 8);
+    for (int l = 1; l <= 7; ++l)
+        if (l != 5) set(l, A_H0 + 16 * (l - 1), 16, 0, 0, G_DPRE0 + 16 * l, 16, 8);
+    set(5, A_PE, 4, A_H0 + 16 * 4, 16, G_DPRE0 + 16 * 5, 16, 8);
+    set(8, A_H0 + 16 * 7, 16, 0, 0, G_DBOTT, 16, 8);         // bottleneck
+    set(9, A_H0 + 16 * 7, 16, 0, 0, G_DA, 1, 1);             // alpha
+    set(10, A_BOTT, 16, A_VPE, 2, G_DV, 8, 4);               // view layer
+    set(11, A_V, 8, 0, 0, G_DC, 1, 1);                       // rgb
+    int tiles = 0, bytes = 0;
+    for (int j = 0; j < kNumJobs; ++j) {
+        jb[j].tile0 = tiles;
+        tiles += jb[j].n_in * jb[j].n_out;
+        bytes += jb[j].x0_k + jb[j].x1_k + jb[j].y_k;
+    }
+    *total_tiles = tiles;
+    int wg = 0;
+    for (int j = 0; j < kNumJobs; ++j) {  // workgroups in proportion to the bytes a job streams
+        int n = (int)((double)(jb[j].x0_k + jb[j].x1_k + jb[j].y_k) / bytes * total_wgs + 0.5);
+        if (n < 1) n = 1;
+        jb[j].wg0 = wg, jb[j].wgs = n;
+        wg += n;
+    }
+}
+
+static int gperm_tiles() {
+    DwJob jb[kNumJobs];
+    int tiles;
+    make_jobs(jb, &tiles, 256);
+    return tiles;
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+NERF_API size_t nerf_mlp_packed_bwd_bytes(void) { return layout::kPackedBwdBytes; }
+
+NERF_API int nerf_mlp_pack_bwd(const float* const* params, void* packed_bwd, nerf_stream_t stream) {
+    NERF_REQUIRE(params && packed_bwd, "nerf_mlp_pack_bwd: null pointer");
+    NERF_REQUIRE(((uintptr_t)packed_bwd & 15) == 0, "nerf_mlp_pack_bwd: packed_bwd must be 16-byte aligned");
+    ParamPtrsB pp;
+    for (int i = 0; i < 24; ++i) {
+        NERF_REQUIRE(params[i], "nerf_mlp_pack_bwd: params[%d] is null", i);
+        pp.p[i] = params[i];
+    }
+    mlp_pack_bwd_kernel<<<layout::B_END, 64, 0, as_stream(stream)>>>(pp, (char*)packed_bwd);
+    return check_launch("nerf_mlp_pack_bwd");
+}
+
+NERF_API size_t nerf_mlp_grad_bytes(int64_t n_points) {
+    const int64_t wave_tiles = (n_points + kPointsPerBlock - 1) / kPointsPerBlock * kWavesPerBlock;
+    return (size_t)wave_tiles * layout::kGradBlocks * layout::kFragBytes;
+}
+
+NERF_API size_t nerf_mlp_partial_bytes(void) { return (size_t)gperm_tiles() * 16 * 64 * sizeof(float); }
+
+NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const float* d_raw,
+                               int64_t n_points, float gscale, void* gbuf, void* partial,
+                               float* const* grads, int accumulate, nerf_stream_t stream) {
+    NERF_REQUIRE(packed_bwd && act && d_raw && gbuf && partial && grads, "nerf_mlp_backward: null pointer");
+    NERF_REQUIRE(n_points >= 0 && gscale > 0.f, "nerf_mlp_backward: bad size or scale");
+    NERF_REQUIRE((((uintptr_t)packed_bwd | (uintptr_t)act | (uintptr_t)d_raw | (uintptr_t)gbuf | (uintptr_t)partial) & 15) == 0,
+                 "nerf_mlp_backward: buffers must be 16-byte aligned");
+    if (n_points == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    const int64_t blocks = (n_points + kPointsPerBlock - 1) / kPointsPerBlock;
+    if (blocks > 0x7fffffffLL) return NERF_FAIL(NERF_E_UNSUPPORTED, "nerf_mlp_backward: too many points");
+    ChainArgs ca{(const char*)packed_bwd, (const char*)act, (const float4*)d_raw, (char*)gbuf, n_points, gscale};
+    mlp_bwd_chain_kernel<<<(unsigned)blocks, 512, 0, st>>>(ca);
+    int rc = check_launch("nerf_mlp_backward(chain)");
+    if (rc) return rc;
+
+    DwArgs da{};
+    da.act = (const char*)act, da.gbuf = (const char*)gbuf, da.gperm = (float*)partial;
+    da.wave_tiles = blocks * kWavesPerBlock;
+    int tiles;
+    int wgs = 256;
+    if (da.wave_tiles < 256 * 4) wgs = (int)(da.wave_tiles / 4 > 12 ? da.wave_tiles / 4 : 12);
+    make_jobs(da.job, &tiles, wgs);
+    hipError_t e = hipMemsetAsync(partial, 0, (size_t)tiles * 16 * 64 * sizeof(float), st);
+    if (e != hipSuccess) return NERF_FAIL((int)e, "nerf_mlp_backward(memset): %s", hipGetErrorString(e));
+    const int total_wgs = da.job[kNumJobs - 1].wg0 + da.job[kNumJobs - 1].wgs;
+    mlp_dw_kernel<<<total_wgs, 512, 0, st>>>(da);
+    rc = check_launch("nerf_mlp_backward(dw)");
+    if (rc) return rc;
+
+    UnpackArgs ua{};
+    ua.gperm = (const float*)partial, ua.inv_scale = 1.0f / gscale, ua.accumulate = accumulate;
+    for (int j = 0; j < kNumJobs; ++j) ua.tile0[j] = da.job[j].tile0, ua.n_in[j] = da.job[j].n_in;
+    static const int dims[12][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
+                                    {256, 256}, {256, 256}, {256, 256}, {283, 128}, {128, 3}, {256, 1}};
+    for (int i = 0; i < 24; ++i) {
+        NERF_REQUIRE(grads[i], "nerf_mlp_backward: grads[%d] is null", i);
+        ua.out.g[i] = grads[i];
+    }
+    for (int i = 0; i < 24; ++i) {
+        const int in_dim = dims[i >> 1][0], out_dim = dims[i >> 1][1];
+        const int count = (i & 1) ? out_dim : in_dim * out_dim;
+        mlp_grad_unpack_kernel<<<(count + 255) / 256, 256, 0, st>>>(ua, i, in_dim, out_dim);
+    }
+    return check_launch("nerf_mlp_backward(unpack)");
+}

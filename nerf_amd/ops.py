@@ -256,3 +256,34 @@ def mlp_forward_train(packed, rays, z, act):
             nv.lib().nerf_mlp_forward_train(nv.ptr(packed), nv.ptr(rays), width, nv.ptr(z), n, S,
                                             nv.ptr(raw), nv.ptr(act), nv.stream()), "nerf_mlp_forward_train"))
     return raw
+
+
+def packed_bwd_bytes():
+    return int(nv.lib().nerf_mlp_packed_bwd_bytes())
+
+
+def mlp_pack_bwd(params, packed_bwd):
+    arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
+    with torch.cuda.device(packed_bwd.device):
+        nv.check(nv.lib().nerf_mlp_pack_bwd(arr, nv.ptr(packed_bwd), nv.stream()), "nerf_mlp_pack_bwd")
+
+
+def grad_bytes(n_points):
+    return int(nv.lib().nerf_mlp_grad_bytes(int(n_points)))
+
+
+def partial_bytes():
+    return int(nv.lib().nerf_mlp_partial_bytes())
+
+
+def mlp_backward(packed_bwd, act, d_raw, gscale, gbuf, partial, grads, accumulate=False):
+    """Parameter gradients (24 tensors shaped like the parameters, written in place) from
+    d_raw [N,S,4] and the activations saved by mlp_forward_train."""
+    n_points = d_raw.numel() // 4
+    if gbuf.numel() < grad_bytes(n_points) or partial.numel() < partial_bytes():
+        raise ValueError("mlp_backward: scratch too small")
+    arr = (ctypes.c_void_p * 24)(*[g.data_ptr() for g in grads])
+    with torch.cuda.device(d_raw.device):
+        nv.check(nv.lib().nerf_mlp_backward(nv.ptr(packed_bwd), nv.ptr(act), nv.ptr(d_raw), n_points,
+                                            float(gscale), nv.ptr(gbuf), nv.ptr(partial), arr,
+                                            int(bool(accumulate)), nv.stream()), "nerf_mlp_backward")

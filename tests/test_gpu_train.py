@@ -81,3 +81,89 @@ def test_forward_train_matches_inference_and_saves_activations(gpu):
             for j in range(8):
                 f = 32 * (k >> 1) + 16 * (k & 1) + 8 * (j >> 2) + 4 * hh + (j & 3)
                 assert abs(h7[k, lane, j] - hcur[c, f]) < 2e-3 * max(1., abs(hcur[c, f])), (k, lane, j)
+
+
+def _decode_blocks(buf, blocks_per_tile, blk0, nk, n_points):
+    """fp16 fragment blocks [wave tile][block][lane][8] -> [points, 16*nk] in feature order."""
+    b = buf.view(-1, blocks_per_tile, 1024)[:, blk0:blk0 + nk].contiguous().view(torch.float16)
+    b = b.view(-1, nk, 64, 8).double().cpu().numpy()
+    k = np.arange(nk)[:, None, None]
+    lane = np.arange(64)[None, :, None]
+    j = np.arange(8)[None, None, :]
+    f = 32 * (k >> 1) + 16 * (k & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
+    c = np.broadcast_to(lane & 31, f.shape)
+    out = np.zeros((b.shape[0] * 32, nk * 16))
+    for t in range(b.shape[0]):
+        out[t * 32 + c, f] = b[t]
+    return out[:n_points]
+
+
+def _mlp_grads_reference(ws, rb, z, d_raw, act):
+    """fp64 torch autograd of sum(raw * d_raw) w.r.t. the 24 parameter arrays.
+
+    A ReLU unit whose pre-activation is within the fp16 forward's rounding of zero may be on in
+    one arithmetic and off in the other; its gradient is then all or nothing.  The backward pass
+    must follow the forward pass it belongs to, so the reference takes the on/off pattern from
+    the activations the GPU forward saved and differentiates pre * mask instead of relu(pre)."""
+    n_points = z.size
+    masks = [torch.tensor(_decode_blocks(act, 158, 4 + 16 * l, 16, n_points) != 0) for l in range(8)]
+    mask_v = torch.tensor(_decode_blocks(act, 158, 148, 8, n_points) != 0)
+    W = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws]
+    r = torch.tensor(rb, dtype=torch.float64)
+    zz = torch.tensor(z, dtype=torch.float64)
+    pts = (r[:, None, 0:3] + r[:, None, 3:6] * zz[:, :, None]).reshape(-1, 3)
+    dirs = r[:, None, 8:11].expand(r.shape[0], zz.shape[1], 3).reshape(-1, 3)
+    pe, ve = trs.embed(pts, 10), trs.embed(dirs, 4)
+    h = pe
+    flips = 0
+    for i in range(8):
+        if i == 5:
+            h = torch.cat([pe, h], -1)
+        pre = h @ W[2 * i] + W[2 * i + 1]
+        flips += int(((pre > 0) != masks[i]).sum())
+        h = pre * masks[i]
+    alpha = h @ W[22] + W[23]
+    bott = h @ W[16] + W[17]
+    pre = torch.cat([bott, ve], -1) @ W[18] + W[19]
+    flips += int(((pre > 0) != mask_v).sum())
+    v = pre * mask_v
+    raw = torch.cat([v @ W[20] + W[21], alpha], -1)
+    (raw * torch.tensor(d_raw, dtype=torch.float64).reshape(-1, 4)).sum().backward()
+    return [w.grad.numpy() for w in W], flips / (n_points * (8 * 256 + 128))
+
+
+@pytest.mark.parametrize("n,S", [(8, 64), (5, 192), (3, 37)])
+def test_mlp_backward(gpu, n, S):
+    from nerf_amd import ops
+    from nerf_amd.run_nerf_helpers import init_nerf_model
+    rng = np.random.default_rng(100 + n)
+    ws = trained_like_weights(rng)
+    m = init_nerf_model(8, 256, 63, 27, 4, [4], True, device=gpu)
+    m.set_weights(ws)
+    rb = synthetic_rays(n, seed=n)
+    rays = _t(rb, gpu)
+    z = ops.sample_z(rays, S)
+    d_raw = (rng.normal(size=(n, S, 4)) * 1e-4).astype(np.float32)
+    act = torch.zeros((ops.act_bytes(n * S),), dtype=torch.uint8, device=gpu)
+    ops.mlp_forward_train(m.packed(), rays, z, act)
+    pb = torch.empty((ops.packed_bwd_bytes(),), dtype=torch.uint8, device=gpu)
+    ops.mlp_pack_bwd([p.detach() for p in m.params], pb)
+    gbuf = torch.empty((ops.grad_bytes(n * S),), dtype=torch.uint8, device=gpu)
+    part = torch.empty((ops.partial_bytes(),), dtype=torch.uint8, device=gpu)
+    grads = [torch.full_like(p, 7.0) for p in m.params]
+    ops.mlp_backward(pb, act, _t(d_raw, gpu), 4096.0, gbuf, part, grads)
+    ref, flip_rate = _mlp_grads_reference(ws, rb, z.cpu().numpy(), d_raw, act)
+    assert flip_rate < 2e-3  # units whose on/off state differs between fp16 and fp64 forward
+    names = [f"{'W' if i % 2 == 0 else 'b'}{i // 2}" for i in range(24)]
+    for name, g, r in zip(names, grads, ref):
+        g = g.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(g)), name
+        # fp16 operands, fp32 accumulation: compare in the norm, plus a loose elementwise bound
+        rel = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
+        assert rel < 5e-3, (name, rel)
+        assert np.max(np.abs(g - r)) < 2e-2 * np.max(np.abs(r)) + 1e-12, name
+    # accumulate mode adds on top
+    grads2 = [g.clone() for g in grads]
+    ops.mlp_backward(pb, act, _t(d_raw, gpu), 4096.0, gbuf, part, grads2, accumulate=True)
+    for a, b in zip(grads, grads2):
+        assert torch.allclose(b, 2 * a, rtol=1e-3, atol=1e-12)
