@@ -165,6 +165,18 @@ int nerf_mlp_backward(const void* packed_bwd, const void* act, const float* d_ra
                       float gscale, void* gbuf, void* partial, float* const* grads, int accumulate,
                       nerf_stream_t stream);
 
+/* img2mse and its gradient (run_nerf_helpers.py:11; run_nerf.py:781,:809): adds
+ * sum((x-y)^2)*inv_count to *loss (which the caller zeroes; may be NULL) and writes
+ * d_x = 2(x-y)*inv_count*upstream (may be NULL).  count = number of scalars. */
+int nerf_mse_loss_fwd_bwd(const float* x, const float* y, int64_t count, float inv_count,
+                          float upstream, float* loss, float* d_x, nerf_stream_t stream);
+
+/* tf.keras.optimizers.Adam dense update (run_nerf.py:605,:826) over a flat buffer of n scalars:
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr_t m/(sqrt(v)+eps), where the caller
+ * passes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (eps is not bias-corrected, as in Keras). */
+int nerf_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, float lr_t,
+                   float beta1, float beta2, float eps, nerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@ import torch
 
 from . import _native as nv
 from . import ops
+from . import training
 from .run_nerf_helpers import NerfModel
 
 
@@ -67,33 +68,38 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     if width < 11:
         raise NotImplementedError("render_rays: the built network needs view directions (ray width 11)")
     fused = getattr(network_query_fn, 'nerf_amd_fused', False)
+    rec = training.recording()  # inside a GradientTape: record for the backward pass
+    if rec and not fused:
+        raise NotImplementedError("render_rays: gradients need the network_query_fn built by create_nerf")
 
     def query(z, net):
+        if rec:
+            return training.MLPQuery.apply(rays, z, net, *net.params)
         if fused:
             return ops.mlp_forward_rays(net.packed(), rays, z)
         pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
         return nv.f32(network_query_fn(pts, rays[:, 8:11], net), rays.device)
 
-    def noise_for(z):
+    def composite(raw, z):
+        noise = None
         if raw_noise_std > 0.:
-            return torch.randn(z.shape, dtype=torch.float32, device=rays.device)
-        return None
+            noise = torch.randn(z.shape, dtype=torch.float32, device=rays.device)
+        if rec:
+            return training.Composite.apply(raw, z, rays, bool(white_bkgd), noise, float(raw_noise_std))
+        return ops.composite_fwd(raw, z, rays[:, 3:6], width, white_bkgd, noise, raw_noise_std)
 
     if perturb > 0. and perturb_u is None:
         perturb_u = torch.rand((n, N_samples), dtype=torch.float32, device=rays.device)
     z_vals = ops.sample_z(rays, N_samples, lindisp, perturb_u if perturb > 0. else None)
     raw = query(z_vals, network_fn)
-    rays_d = rays[:, 3:6]
-    rgb_map, disp_map, acc_map, weights, depth_map = ops.composite_fwd(
-        raw, z_vals, rays_d, width, white_bkgd, noise_for(z_vals), raw_noise_std)
+    rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals)
     ret = {}
     if N_importance > 0:
         ret.update(rgb0=rgb_map, disp0=disp_map, acc0=acc_map)
-        z_vals, _, z_std = ops.resample_merge(z_vals, weights, N_importance, det=(perturb == 0.),
+        z_vals, _, z_std = ops.resample_merge(z_vals, weights.detach(), N_importance, det=(perturb == 0.),
                                               u=pdf_u, want_samples=False)
         raw = query(z_vals, network_fine if network_fine is not None else network_fn)
-        rgb_map, disp_map, acc_map, weights, depth_map = ops.composite_fwd(
-            raw, z_vals, rays_d, width, white_bkgd, noise_for(z_vals), raw_noise_std)
+        rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals)
         ret['z_std'] = z_std
     ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map, depth_map=depth_map)
     if retraw:

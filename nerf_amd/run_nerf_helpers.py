@@ -4,6 +4,8 @@ Same names, argument meaning and return structure as the reference (file:line ci
 function), so `from nerf_amd.run_nerf_helpers import *` can replace the reference's star import
 (run_nerf.py:7).  All arithmetic runs in libnerfhip.so on the GPU.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -16,8 +18,9 @@ __all__ = ["img2mse", "mse2psnr", "to8b", "Embedder", "get_embedder", "NerfModel
 
 # ---- misc (run_nerf_helpers.py:11-17) ----------------------------------------------------------
 def img2mse(x, y):
-    """run_nerf_helpers.py:11"""
-    return torch.mean(torch.square(x - y))
+    """run_nerf_helpers.py:11 -- mean squared error over every element (differentiable in x)."""
+    from .training import mse
+    return mse(x, y)
 
 
 def mse2psnr(x):
@@ -69,6 +72,11 @@ def get_embedder(multires, i=0):
 
 
 # ---- model (run_nerf_helpers.py:80-117) --------------------------------------------------------
+# flat-buffer address -> model, so that an optimiser that updates the buffer with a raw kernel can
+# tell the owner to re-pack its weights
+_MODELS_BY_STORAGE = weakref.WeakValueDictionary()
+
+
 class NerfModel:
     """What init_nerf_model returns: the parameters of one network with the slice of the Keras
     Model interface create_nerf and train() use (get_weights / set_weights / trainable_variables,
@@ -89,6 +97,8 @@ class NerfModel:
         self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
         self.skips, self.use_viewdirs = tuple(skips), use_viewdirs
         dev = ops._dev() if device is None else torch.device(device)
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
         self.device = dev
         self.shapes = []
         k = input_ch
@@ -96,14 +106,30 @@ class NerfModel:
             self.shapes.append((k, W))
             k = W + input_ch if i in skips else W
         self.shapes += [(k, 256), (256 + input_ch_views, W // 2), (W // 2, 3), (k, 1)]
+        # one flat fp32 buffer holds every parameter (the fused Adam kernel updates it in one
+        # launch); the 24 tensors handed out are views into it
+        sizes = []
+        for (fi, fo) in self.shapes:
+            sizes += [fi * fo, fo]
+        self.flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
         self.params = []
-        for (fi, fo) in self.shapes:  # Keras Dense defaults: glorot-uniform kernel, zero bias (:83)
+        at = 0
+        for k, (fi, fo) in enumerate(self.shapes):  # Keras Dense defaults: glorot-uniform kernel, zero bias (:83)
             lim = float(np.sqrt(6. / (fi + fo)))
-            w = (torch.rand((fi, fo), dtype=torch.float32, device=dev, generator=generator) * 2 - 1) * lim
+            w = self.flat[at:at + fi * fo].view(fi, fo)
+            w.copy_((torch.rand((fi, fo), dtype=torch.float32, device=dev, generator=generator) * 2 - 1) * lim)
+            at += fi * fo
+            bvec = self.flat[at:at + fo]
+            at += fo
             self.params.append(w.requires_grad_(True))
-            self.params.append(torch.zeros((fo,), dtype=torch.float32, device=dev, requires_grad=True))
-        self._packed = torch.empty((ops.packed_bytes(),), dtype=torch.uint8, device=dev)
+            self.params.append(bvec.requires_grad_(True))
+        self._packed = torch.empty((ops.packed_bytes(),), dtype=torch.uint8, device=dev) if dev.type == 'cuda' else None
+        self._packed_bwd = None
         self._packed_version = None
+        self._packed_bwd_version = None
+        self._epoch = 0          # bumped by updates that bypass torch (the fused Adam kernel)
+        self.grad_scale = 65536.0  # factor applied to d_raw before the fp16 gradient chain
+        _MODELS_BY_STORAGE[self.flat.data_ptr()] = self
 
     # Keras-like surface
     @property
@@ -123,22 +149,37 @@ class NerfModel:
                 if tuple(w.shape) != tuple(p.shape):
                     raise ValueError(f"set_weights: shape {tuple(w.shape)} does not match {tuple(p.shape)}")
                 p.copy_(w)
-        self._packed_version = None
+        self.mark_dirty()
 
     def count_params(self):
         return sum(p.numel() for p in self.params)
 
+    def _version(self):
+        return (self._epoch,) + tuple(p._version for p in self.params)
+
     def packed(self):
         """The fp16 fragment stream for the current parameter values (re-packed when they change)."""
-        ver = tuple(p._version for p in self.params)
+        ver = self._version()
         if ver != self._packed_version:
             with torch.no_grad():
                 ops.mlp_pack([p.detach() for p in self.params], self._packed)
             self._packed_version = ver
         return self._packed
 
+    def packed_bwd(self):
+        """The transposed stream the gradient chain reads."""
+        ver = self._version()
+        if self._packed_bwd is None:
+            self._packed_bwd = torch.empty((ops.packed_bwd_bytes(),), dtype=torch.uint8, device=self.device)
+        if ver != self._packed_bwd_version:
+            with torch.no_grad():
+                ops.mlp_pack_bwd([p.detach() for p in self.params], self._packed_bwd)
+            self._packed_bwd_version = ver
+        return self._packed_bwd
+
     def mark_dirty(self):
-        self._packed_version = None
+        """Call after writing the parameters behind torch's back (raw kernels on self.flat)."""
+        self._epoch += 1
 
 
 def init_nerf_model(D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4],
