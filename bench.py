@@ -70,6 +70,46 @@ def cpu_baseline(n_rays, seed=0):
     return n_rays / dt, dt
 
 
+def train_leg(a, kw_train, models, dev, rank, world, fence):
+    """Optimisation steps as run_nerf.py:770-826 performs them (N_rand rays per GPU, 64+128 samples,
+    perturb=1, fwd + bwd + Keras Adam; gradients all-reduced over the ranks).  Weak scaling: the
+    global batch is N_rand x n_gpus."""
+    from nerf_amd import training
+    from nerf_amd.run_nerf import render
+    kw = dict(kw_train)
+    kw['perturb'] = 1.
+    grad_vars = models['model'].trainable_variables + models['model_fine'].trainable_variables
+    o, d = synthetic_batch(a.n_rand, 5000 + rank, dev)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(77 + rank)
+    target = torch.rand((a.n_rand, 3), generator=g).to(dev)
+    for m in models.values():
+        m.grad_scale = float(2 ** round(np.log2(48.0 * a.n_rand * world * 16)))
+    opt = training.Adam(training.ExponentialDecay(5e-4, 500 * 1000, 0.1))
+    fn = lambda r: render(1, 1, 1., chunk=1024 * 32, rays=r, near=2., far=6., retraw=True, **kw)
+    for _ in range(3):
+        loss, _, _ = training.train_step(fn, (o, d), target, grad_vars, opt)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.train_steps):
+        loss, _, _ = training.train_step(fn, (o, d), target, grad_vars, opt)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert np.isfinite(float(loss)), "training produced a non-finite loss"
+    rays_per_s = world * a.n_rand * a.train_steps / dt
+    flop_per_ray = 3 * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_PER_POINT  # fwd + dX + dW
+    return {"rays_per_s": round(rays_per_s, 1), "ms_per_step": round(dt / a.train_steps * 1e3, 3),
+            "steps": a.train_steps, "n_rand_per_gpu": a.n_rand, "scaling": "weak",
+            "algorithmic_tflops": round(rays_per_s * flop_per_ray / 1e12, 2),
+            "frac_of_mfma_peak": round(rays_per_s * flop_per_ray / 1e12 / MFMA_PEAK_TFLOPS / world, 4),
+            "final_loss": round(float(loss), 6)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +118,8 @@ def main():
     ap.add_argument("--rays", type=int, default=N_RAYS, help="rays per GPU per step")
     ap.add_argument("--chunk", type=int, default=1024 * 128, help="rays per render_rays call")
     ap.add_argument("--cpu-rays", type=int, default=16384, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed optimisation steps of the training leg (0 = skip)")
+    ap.add_argument("--n-rand", type=int, default=4096, help="rays per GPU per optimisation step")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +172,10 @@ def main():
         dt = float(t.item())
     assert bool(torch.isfinite(rgb).all()), "render produced non-finite colours"
 
+    train = None
+    if a.train_steps > 0:
+        train = train_leg(a, kw_train, models, dev, rank, world, fence)
+
     mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
     mlp_points = sum(p for _, _, p in timing)
     achieved = mlp_points * FLOP_PER_POINT / (mlp_ms * 1e-3) / 1e12
@@ -159,6 +205,7 @@ def main():
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": mlp_points // max(1, len(timing)),
                          "mlp_share_of_step": round(mlp_ms * 1e-3 / dt, 4)},
             "cpu_baseline": cpu,
+            "train": train,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -102,6 +102,21 @@ DEV void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// The same load issued from inline asm, so that the compiler does not know about it: where LDS
+// addresses are not compile-time constants it cannot tell later LDS reads from loads still in
+// flight and would drain the whole queue (s_waitcnt vmcnt(0)) before every read.  The caller
+// owns the ordering: a counted s_waitcnt vmcnt, then a barrier if other waves read the data.
+// lds_dst must be wave-uniform.
+DEV void glds16_untracked(const void* gsrc, void* lds_dst) {
+    const unsigned addr = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(addr)
+                 : "memory");
+}
+
 // The weight stream (NCHUNKS chunks of 16 KiB, RING LDS slots, DEPTH chunks in flight) and the
 // register pipeline of A fragments.  Fragments must be taken in stream order, F = 0, 1, 2, ...
 template <int NCHUNKS, int RING, int DEPTH>

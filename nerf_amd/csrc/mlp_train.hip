@@ -211,17 +211,17 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
 // ---------------------------------------------------------------------------------------------
 // 2. weight gradients
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxInTiles = 11;   // layer 5: 2 (encoding) + 8 (h4) + 1 (ones column for the bias)
-constexpr int kMaxXBlocks = 20, kMaxYBlocks = 16;
+constexpr int kMaxInTiles = 9;    // 8 tiles of a 256-wide input + 1 (ones column for the bias)
+constexpr int kMaxXBlocks = 16, kMaxYBlocks = 16;
 constexpr int kDwStageBytes = (kMaxXBlocks + kMaxYBlocks) * kFragBytes;  // 36 KiB
-constexpr int kDwStages = 3;
-constexpr int kNumJobs = 12;
+constexpr int kDwStages = 4;
+constexpr int kNumJobs = 14;  // layers 5 and 9 have two input segments: one job each
 
 struct DwJob {
-    int x0_blk, x0_k;    // first input segment: block in the activation buffer, k-steps
-    int x1_blk, x1_k;    // second input segment (0 k-steps if none)
+    int x0_blk, x0_k;    // input segment: block in the activation buffer, k-steps
+    int bias;            // 1: a trailing ones tile yields the bias gradient
     int y_blk, y_k;      // gradient segment: block in the gradient buffer, k-steps (1 or even)
-    int n_in;            // input tiles including the trailing ones tile
+    int n_in;            // input tiles including the ones tile
     int n_out;           // output tiles (<= 8): wave w owns output tile w
     int tile0;           // first 32x32 tile of this job in the partial-sum buffer
     int wg0, wgs;        // workgroups [wg0, wg0 + wgs) split the wave tiles of this job
@@ -237,100 +237,126 @@ struct DwArgs {
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
-// Operand fragment (A or B alike) of the 32 features of blocks (blk, blk+1) x the 16 points
-// 16*kp .. 16*kp+15 of a staged wave tile: lane (r = feature slot, hh) gets points 8*hh .. 8*hh+7.
-// `one_block`: the segment has a single k-step; the upper 16 feature slots read as zero.
-DEV half8 tr_operand(const char* stage, int blk, int kp, int lane, bool one_block) {
+// LDS image of one 32-feature tile (a pair of stored blocks) of a staged wave tile: 2 KiB laid
+// out [point][block of the pair][lane half][8 features], 64 B per point, so that the 32 lanes
+// of a half-wave, which read 4 points x 64 B with one transposing read, touch every bank once.
+// The direct-to-LDS load writes lane-linear, so the permutation is applied to the SOURCE
+// address: LDS lane L of load n (n = 0, 1) fetches point 16n + L/4, block (L>>1)&1, half L&1.
+constexpr int kTileImgBytes = 2 * kFragBytes;
+
+DEV void stage_tile(const char* blocks /*lane-independent address of the pair's first block*/,
+                    char* img, int n, int lane, bool one_block) {
+    const int c = 16 * n + (lane >> 2), sb = one_block ? 0 : (lane >> 1) & 1, hh = lane & 1;
+    glds16_untracked(blocks + sb * kFragBytes + (32 * hh + c) * 16, img + n * kFragBytes);
+}
+
+// Operand fragment (A or B alike) of a staged tile image x the 16 points 16*kp .. 16*kp+15:
+// lane (r = feature slot, hh) gets points 8*hh .. 8*hh+7 of the 16.  `one_block`: the segment
+// has a single k-step; the upper 16 feature slots read as zero.
+DEV half8 tr_operand(const char* img, int kp, int lane, bool one_block) {
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int s = blk + (g & 1);
     const int c = 16 * kp + 8 * (g >> 1) + q;
-    const char* base = stage + s * kFragBytes + (32 * (p >> 1) + c) * 16 + 8 * (p & 1);
+    const char* base = img + c * 64 + (g & 1) * 32 + (p >> 1) * 16 + (p & 1) * 8;
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)base);
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + 4 * 16));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + 4 * 64));
     short8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if (one_block && (g & 1)) v = (short8)0;
     return __builtin_bit_cast(half8, v);
 }
 
-__global__ __launch_bounds__(512) void mlp_dw_kernel(DwArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[kDwStages * kDwStageBytes];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // which job / slice this workgroup owns
-    int ji = 0;
-#pragma unroll
-    for (int j = 1; j < kNumJobs; ++j)
-        if ((int)blockIdx.x >= a.job[j].wg0) ji = j;
-    const DwJob jb = a.job[ji];
+// One workgroup's share of a job with NX input tiles (+ the ones tile when BIAS).
+template <int NX, int BIAS>
+DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave) {
+    constexpr int NI = NX + BIAS;
     const int slice = blockIdx.x - jb.wg0;
     const int64_t per = (a.wave_tiles + jb.wgs - 1) / jb.wgs;
     const int64_t t_lo = slice * per, t_hi = (t_lo + per < a.wave_tiles) ? t_lo + per : a.wave_tiles;
-    const int xk = jb.x0_k + jb.x1_k, nblk = xk + jb.y_k;
+    const bool y_one = jb.y_k == 1;
+    const int ny = (jb.y_k + 1) / 2;        // gradient tiles
+    const int nunit = 2 * (NX + ny);        // 1 KiB loads per staged wave tile
 
-    // stage one wave tile: blocks are dealt round-robin to the 8 waves, 1 KiB per wave-load
-    auto stage_in = [&](int64_t wt, int buf) -> int {
-        char* dst = lds + buf * kDwStageBytes;
-        const char* ab = a.act + (size_t)wt * kActBlocks * kFragBytes + lane * 16;
-        const char* gb = a.gbuf + (size_t)wt * kGradBlocks * kFragBytes + lane * 16;
-        int mine = 0;
-        for (int b = wave; b < nblk; b += kWavesPerBlock) {
-            const char* src = (b < jb.x0_k) ? ab + (size_t)(jb.x0_blk + b) * kFragBytes
-                            : (b < xk)      ? ab + (size_t)(jb.x1_blk + b - jb.x0_k) * kFragBytes
-                                            : gb + (size_t)(jb.y_blk + b - xk) * kFragBytes;
-            glds16(src, dst + b * kFragBytes);
-            ++mine;
+    // stage one wave tile: loads are dealt round-robin to the 8 waves
+    auto stage_in = [&](int64_t wt, int sbuf) {
+        char* dst = lds + sbuf * kDwStageBytes;
+        const char* ab = a.act + ((size_t)wt * kActBlocks + jb.x0_blk) * kFragBytes;
+        const char* gb = a.gbuf + ((size_t)wt * kGradBlocks + jb.y_blk) * kFragBytes;
+        for (int u = wave; u < nunit; u += kWavesPerBlock) {
+            const int img = u >> 1;
+            if (img < NX) stage_tile(ab + (size_t)img * kTileImgBytes, dst + img * kTileImgBytes, u & 1, lane, false);
+            else stage_tile(gb + (size_t)(img - NX) * kTileImgBytes, dst + img * kTileImgBytes, u & 1, lane, y_one);
         }
-        return mine;
     };
 
-    f32x16 acc[kMaxInTiles];
+    f32x16 acc[NI];
 #pragma unroll
-    for (int i = 0; i < kMaxInTiles; ++i)
+    for (int i = 0; i < NI; ++i)
         acc[i] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // constant operand of the ones column: input slot 0 is 1 for every point
     half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((lane & 31) == 0) ones = half8{1, 1, 1, 1, 1, 1, 1, 1};
 
     const int64_t ntile = t_hi - t_lo;
-    int inflight[kDwStages] = {0, 0, 0};   // loads this wave issued per staged tile
-    if (ntile > 0) inflight[0] = stage_in(t_lo, 0);
-    if (ntile > 1) inflight[1] = stage_in(t_lo + 1, 1);
-    for (int64_t it = 0; it < ntile; ++it) {
-        const int buf = (int)(it % kDwStages);
-        // everything but the next tile's loads has landed
-        wait_vmcnt_n((it + 1 < ntile) ? inflight[(it + 1) % kDwStages] : 0);
-        asm volatile("s_barrier" ::: "memory");
-        // the buffer read two iterations ago is free again (every wave passed the barrier above)
-        if (it + 2 < ntile) inflight[(it + 2) % kDwStages] = stage_in(t_lo + it + 2, (int)((it + 2) % kDwStages));
-        if (wave < jb.n_out) {
-            const char* stage = lds + buf * kDwStageBytes;
-            const bool y_one = jb.y_k == 1;
+    // every staged tile costs this wave the same number of loads
+    const int mine = (nunit - wave + kWavesPerBlock - 1) / kWavesPerBlock;
+    constexpr int kAhead = kDwStages - 1;  // wave tiles in flight beyond the one being consumed
 #pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                const half8 ya = tr_operand(stage, xk + 2 * wave, kp, lane, y_one);
-                static_for<0, kMaxInTiles>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    if (i < jb.n_in - 1) {
-                        const half8 xb = tr_operand(stage, 2 * i, kp, lane, false);
-                        acc[i] = mfma(ya, xb, acc[i]);
-                    } else if (i == jb.n_in - 1) {
-                        acc[i] = mfma(ya, ones, acc[i]);
+    for (int k = 0; k < kAhead; ++k)
+        if (k < ntile) stage_in(t_lo + k, k);
+    // The stage loop is unrolled over the ring so that every LDS address is a compile-time
+    // offset: with a run-time buffer index the compiler cannot tell the transposing reads from
+    // the direct-to-LDS loads still in flight and drains the whole queue before every read.
+    for (int64_t it0 = 0; it0 < ntile; it0 += kDwStages) {
+        static_for<0, kDwStages>([&](auto sc) {
+            constexpr int buf = decltype(sc)::value;
+            const int64_t it = it0 + buf;
+            if (it < ntile) {
+                // everything but the loads of the tiles after this one has landed
+                const int64_t later = (ntile - 1 - it < kAhead - 1) ? ntile - 1 - it : kAhead - 1;
+                wait_vmcnt_n((int)later * mine);
+                asm volatile("s_barrier" ::: "memory");
+                // the buffer read in the previous iteration is free again (every wave passed the barrier)
+                constexpr int nbuf = (buf + kAhead) % kDwStages;
+                if (it + kAhead < ntile) stage_in(t_lo + it + kAhead, nbuf);
+                if (wave < jb.n_out) {
+                    const char* stage = lds + buf * kDwStageBytes;
+#pragma unroll
+                    for (int kp = 0; kp < 2; ++kp) {
+                        const half8 ya = tr_operand(stage + (NX + wave) * kTileImgBytes, kp, lane, y_one);
+#pragma unroll
+                        for (int i = 0; i < NX; ++i)
+                            acc[i] = mfma(ya, tr_operand(stage + i * kTileImgBytes, kp, lane, false), acc[i]);
+                        if constexpr (BIAS) acc[NX] = mfma(ya, ones, acc[NX]);
                     }
-                });
-            }
-        }
-    }
-    // add this workgroup's partial dW^T to the global buffer (256 contiguous bytes per register)
-    if (wave < jb.n_out && ntile > 0) {
-        static_for<0, kMaxInTiles>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (i < jb.n_in) {
-                float* dst = a.gperm + ((size_t)(jb.tile0 + wave * jb.n_in + i) * 16) * 64 + lane;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, acc[i][r]);
+                }
             }
         });
     }
+    // add this workgroup's partial dW^T to the global buffer (256 contiguous bytes per register)
+    if (wave < jb.n_out && ntile > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float* dst = a.gperm + ((size_t)(jb.tile0 + wave * NI + i) * 16) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, acc[i][r]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void mlp_dw_kernel(DwArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[kDwStages * kDwStageBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int ji = 0;  // which job this workgroup belongs to
+#pragma unroll
+    for (int j = 1; j < kNumJobs; ++j)
+        if ((int)blockIdx.x >= a.job[j].wg0) ji = j;
+    const DwJob jb = a.job[ji];
+    const int nx = jb.x0_k / 2;
+    if (nx == 8 && jb.bias) dw_body<8, 1>(a, jb, lds, lane, wave);
+    else if (nx == 8) dw_body<8, 0>(a, jb, lds, lane, wave);
+    else if (nx == 2) dw_body<2, 1>(a, jb, lds, lane, wave);
+    else if (nx == 4) dw_body<4, 1>(a, jb, lds, lane, wave);
+    else dw_body<1, 0>(a, jb, lds, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -379,47 +405,51 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a, int pi, int in_dim, int out
     if (e >= count) return;
     const int layer = pi >> 1;  // 0..7 point layers, 8 bottleneck, 9 view, 10 rgb, 11 alpha
     const int in = is_bias ? -1 : e / out_dim, out = is_bias ? e : e % out_dim;
-    // job of each layer: 0..7 -> jobs 0..7, bottleneck 8, alpha 9, view 10, rgb 11
-    const int job = layer <= 8 ? layer : (layer == 9 ? 10 : (layer == 10 ? 11 : 9));
+    // jobs: 0..7 = point layers (layer 5: its encoding rows + bias), 8 bottleneck, 9 alpha,
+    // 10 view layer (bottleneck rows + bias), 11 rgb, 12 = layer 5's h4 rows, 13 = view layer's
+    // view-encoding rows
+    int job = layer <= 8 ? layer : (layer == 9 ? 10 : (layer == 10 ? 11 : 9));
     int ot, orow, it, irow;
     if (layer == 10 || layer == 11) ot = 0, orow = out;           // d rgb slots 0..2 / d alpha slot 0
     else acc_slot(out, ot, orow);
-    const int n_in = a.n_in[job];
-    if (is_bias) it = n_in - 1, irow = 0;
+    if (is_bias) it = a.n_in[job] - 1, irow = 0;
     else if (layer == 0) enc_slot(in, 5, it, irow);
-    else if (layer == 5) { if (in < 63) enc_slot(in, 5, it, irow); else { acc_slot(in - 63, it, irow); it += 2; } }
-    else if (layer == 9) { if (in < 256) acc_slot(in, it, irow); else { enc_slot(in - 256, 2, it, irow); it += 8; } }
+    else if (layer == 5) { if (in < 63) enc_slot(in, 5, it, irow); else { acc_slot(in - 63, it, irow); job = 12; } }
+    else if (layer == 9) { if (in < 256) acc_slot(in, it, irow); else { enc_slot(in - 256, 2, it, irow); job = 13; } }
     else acc_slot(in, it, irow);
+    const int n_in = a.n_in[job];
     const int reg = (orow & 3) + 4 * (orow >> 3), lane = 32 * ((orow >> 2) & 1) + irow;
     const float v = a.gperm[((size_t)(a.tile0[job] + ot * n_in + it) * 16 + reg) * 64 + lane] * a.inv_scale;
     float* dst = a.out.g[pi] + e;
     *dst = a.accumulate ? *dst + v : v;
 }
 
-// the twelve (layer input, layer gradient) products
+// the (layer input segment, layer gradient) products
 static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs) {
-    auto set = [&](int j, int x0b, int x0k, int x1b, int x1k, int yb, int yk, int n_out) {
-        jb[j].x0_blk = x0b, jb[j].x0_k = x0k, jb[j].x1_blk = x1b, jb[j].x1_k = x1k;
-        jb[j].y_blk = yb, jb[j].y_k = yk, jb[j].n_in = (x0k + x1k) / 2 + 1, jb[j].n_out = n_out;
+    auto set = [&](int j, int xb, int xk, int bias, int yb, int yk, int n_out) {
+        jb[j].x0_blk = xb, jb[j].x0_k = xk, jb[j].bias = bias;
+        jb[j].y_blk = yb, jb[j].y_k = yk, jb[j].n_in = xk / 2 + bias, jb[j].n_out = n_out;
     };
-    set(0, A_PE, 4, 0, 0, G_DPRE0, 16, 8);
+    set(0, A_PE, 4, 1, G_DPRE0, 16, 8);
     for (int l = 1; l <= 7; ++l)
-        if (l != 5) set(l, A_H0 + 16 * (l - 1), 16, 0, 0, G_DPRE0 + 16 * l, 16, 8);
-    set(5, A_PE, 4, A_H0 + 16 * 4, 16, G_DPRE0 + 16 * 5, 16, 8);
-    set(8, A_H0 + 16 * 7, 16, 0, 0, G_DBOTT, 16, 8);         // bottleneck
-    set(9, A_H0 + 16 * 7, 16, 0, 0, G_DA, 1, 1);             // alpha
-    set(10, A_BOTT, 16, A_VPE, 2, G_DV, 8, 4);               // view layer
-    set(11, A_V, 8, 0, 0, G_DC, 1, 1);                       // rgb
+        if (l != 5) set(l, A_H0 + 16 * (l - 1), 16, 1, G_DPRE0 + 16 * l, 16, 8);
+    set(5, A_PE, 4, 1, G_DPRE0 + 16 * 5, 16, 8);             // layer 5, encoding rows + bias
+    set(12, A_H0 + 16 * 4, 16, 0, G_DPRE0 + 16 * 5, 16, 8);  // layer 5, h4 rows
+    set(8, A_H0 + 16 * 7, 16, 1, G_DBOTT, 16, 8);            // bottleneck
+    set(9, A_H0 + 16 * 7, 16, 1, G_DA, 1, 1);                // alpha
+    set(10, A_BOTT, 16, 1, G_DV, 8, 4);                      // view layer, bottleneck rows + bias
+    set(13, A_VPE, 2, 0, G_DV, 8, 4);                        // view layer, view-encoding rows
+    set(11, A_V, 8, 1, G_DC, 1, 1);                          // rgb
     int tiles = 0, bytes = 0;
     for (int j = 0; j < kNumJobs; ++j) {
         jb[j].tile0 = tiles;
         tiles += jb[j].n_in * jb[j].n_out;
-        bytes += jb[j].x0_k + jb[j].x1_k + jb[j].y_k;
+        bytes += jb[j].x0_k + jb[j].y_k;
     }
     *total_tiles = tiles;
     int wg = 0;
     for (int j = 0; j < kNumJobs; ++j) {  // workgroups in proportion to the bytes a job streams
-        int n = (int)((double)(jb[j].x0_k + jb[j].x1_k + jb[j].y_k) / bytes * total_wgs + 0.5);
+        int n = (int)((double)(jb[j].x0_k + jb[j].y_k) / bytes * total_wgs + 0.5);
         if (n < 1) n = 1;
         jb[j].wg0 = wg, jb[j].wgs = n;
         wg += n;
@@ -479,7 +509,7 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     da.wave_tiles = blocks * kWavesPerBlock;
     int tiles;
     int wgs = 256;
-    if (da.wave_tiles < 256 * 4) wgs = (int)(da.wave_tiles / 4 > 12 ? da.wave_tiles / 4 : 12);
+    if (da.wave_tiles < 256 * 4) wgs = (int)(da.wave_tiles / 4 > kNumJobs ? da.wave_tiles / 4 : kNumJobs);
     make_jobs(da.job, &tiles, wgs);
     hipError_t e = hipMemsetAsync(partial, 0, (size_t)tiles * 16 * 64 * sizeof(float), st);
     if (e != hipSuccess) return NERF_FAIL((int)e, "nerf_mlp_backward(memset): %s", hipGetErrorString(e));
