@@ -139,8 +139,8 @@ struct Stream {
     DEV void issue() {
         const char* g = gsrc + (size_t)C * kChunkBytes;
         char* l = lds + (C % RING) * kChunkBytes + wave_off;
-        glds16(g, l);
-        glds16(g + kFragBytes, l + kFragBytes);
+        glds16_untracked(g, l);
+        glds16_untracked(g + kFragBytes, l + kFragBytes);
         vm.issued += 2;
         mark[C % RING] = vm.issued;
     }

@@ -44,41 +44,91 @@ constexpr int kDepth = 6;   // chunks in flight ahead of the chunk being synchro
 using FwdStream = Stream<kChunks, kRing, kDepth>;
 constexpr int kRingBytes = FwdStream::kRingBytes;
 
-// One output tile: NK k-steps of fragments F0.., bias tile BT.  getB(k) is the B fragment of k.
-template <int F0, int NK, int BT, class GetB>
-DEV f32x16 run_tile(FwdStream& st, const char* bias, GetB&& getB) {
-    f32x16 acc = load_bias_tile<BT>(bias);
-    static_for<0, NK>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        acc = mfma(st.template take<F0 + k>(), getB(kc), acc);
-    });
-    return acc;
-}
-
 // Where a training forward saves its fragments: [wave tile][block][lane] (null: inference).
 struct ActSink {
     char* base;  // this lane's address inside block 0 of its wave tile
     template <int BLK>
-    DEV void put(VmQueue& vm, const half8& v) const {
+    DEV void put(const half8& v) const {
         *(half8*)(base + BLK * kFragBytes) = v;  // stores are not counted: see VmQueue
-        (void)vm;
     }
 };
 
-// One layer of NT output tiles; tile t becomes fragments 2t, 2t+1 of `out` (and, when STORE,
-// blocks ABLK + 2t, ABLK + 2t + 1 of the saved activations).
-template <int F0, int NT, int NK, int BT0, bool RELU, bool STORE, int ABLK, class GetB>
-DEV void run_layer(FwdStream& st, const char* bias, const ActSink& sink, half8* out, GetB&& getB) {
-    static_for<0, NT>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const f32x16 acc = run_tile<F0 + t * NK, NK, BT0 + t>(st, bias, getB);
-        out[2 * t] = to_frag<0, RELU>(acc);
-        out[2 * t + 1] = to_frag<1, RELU>(acc);
-        if constexpr (STORE) {
-            sink.template put<ABLK + 2 * t>(st.vm, out[2 * t]);
-            sink.template put<ABLK + 2 * t + 1>(st.vm, out[2 * t + 1]);
+// What happens to a finished accumulator tile.  The work is cut into eight slices that run
+// between the MFMAs of the FOLLOWING tile, so that no wave ever sits in a block of conversion
+// instructions while the matrix pipe idles (and the last MFMA's result latency is never exposed).
+struct NoPrev {
+    static constexpr bool kActive = false;
+    template <int S> DEV void slice(const f32x16&) const {}
+};
+// Registers 2S, 2S+1 -> packed dword S&3 of fragment S>>2: round to nearest even, clamped to the
+// fp16 range; RELU folds the activation into the clamp (one v_med3_f32).
+template <bool RELU, bool STORE, int BLK>
+struct ToFrags {
+    static constexpr bool kActive = true;
+    half8* dst;
+    ActSink sink;
+    template <int S> DEV void slice(const f32x16& v) const {
+        const float lo = RELU ? 0.f : -65504.f;
+        const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * S], lo, 65504.f),
+                         __builtin_amdgcn_fmed3f(v[2 * S + 1], lo, 65504.f)};
+        const half2v p = __builtin_convertvector(x, half2v);
+        half8& f = dst[S >> 2];
+        f[2 * (S & 3)] = p[0], f[2 * (S & 3) + 1] = p[1];
+        if constexpr (STORE && (S & 3) == 3) sink.template put<BLK + (S >> 2)>(f);
+    }
+};
+struct KeepRow0 {
+    static constexpr bool kActive = true;
+    float* out;
+    template <int S> DEV void slice(const f32x16& v) const {
+        if constexpr (S == 0) *out = v[0];
+    }
+};
+
+struct Pipe {
+    FwdStream& st;
+    const char* bias;
+    f32x16 acc[2];  // tile T accumulates in acc[T & 1] while tile T-1 is converted out of the other
+};
+
+// Slices of the previous tile done after k-step K of a tile of NK steps: [first, last).
+constexpr int slices_per_step(int nk) { return nk >= 10 ? 1 : nk == 8 ? 2 : 3; }
+constexpr int first_slice_step(int nk) { return nk >= 10 ? 2 : 1; }
+constexpr int last_slice_step(int nk) { return first_slice_step(nk) + 7 / slices_per_step(nk); }
+constexpr int bias_step(int nk) { return last_slice_step(nk) > nk - 4 ? last_slice_step(nk) : nk - 4; }
+static_assert(last_slice_step(4) < 4 && last_slice_step(8) < 6 && last_slice_step(16) < 14, "slice schedule");
+
+// Output tile T (= its bias tile): NK k-steps of fragments F0..; getB(k) is the B fragment of k.
+// Every k-step is one scheduling region: MFMA, the LDS read of the A fragment kPrefetch steps
+// ahead, a slice of the previous tile and, late in the tile, the bias seed of the next one.
+template <int F0, int NK, int T, class GetB, class Prev>
+DEV void run_tile(Pipe& p, GetB&& getB, const Prev& prev) {
+    static_for<0, NK>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        p.acc[T & 1] = mfma(p.st.template take<F0 + k>(), getB(kc), p.acc[T & 1]);
+        if constexpr (Prev::kActive) {
+            constexpr int sp = slices_per_step(NK), s0 = (k - first_slice_step(NK)) * sp;
+            if constexpr (k >= first_slice_step(NK))
+                static_for<(s0 < 8 ? s0 : 8), (s0 + sp < 8 ? s0 + sp : 8)>(
+                    [&](auto sc) { prev.template slice<decltype(sc)::value>(p.acc[(T & 1) ^ 1]); });
         }
+        if constexpr (k == bias_step(NK) && T + 1 < BT_END)
+            p.acc[(T & 1) ^ 1] = load_bias_tile<T + 1>(p.bias);
+        __builtin_amdgcn_sched_barrier(0);
     });
+}
+
+// One layer of NT output tiles; tile t becomes fragments 2t, 2t+1 of `out` (and, when STORE,
+// blocks ABLK + 2t, ABLK + 2t + 1 of the saved activations).  `before` finishes the tile that
+// preceded the layer; the returned object finishes the layer's last tile.
+template <int F0, int NT, int NK, int T0, bool RELU, bool STORE, int ABLK, class GetB, class Prev>
+DEV auto run_layer(Pipe& p, const ActSink& sink, half8* out, GetB&& getB, const Prev& before) {
+    run_tile<F0, NK, T0>(p, getB, before);
+    static_for<1, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        run_tile<F0 + t * NK, NK, T0 + t>(p, getB, ToFrags<RELU, STORE, ABLK + 2 * (t - 1)>{out + 2 * (t - 1), sink});
+    });
+    return ToFrags<RELU, STORE, ABLK + 2 * (NT - 1)>{out + 2 * (NT - 1), sink};
 }
 
 template <int MODE, bool STORE>
@@ -132,8 +182,8 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(FwdArgs a) {
     if constexpr (STORE) {
         const int64_t wave_tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
         sink.base = a.act + (size_t)wave_tile * kActBlocks * kFragBytes + lane * 16;
-        static_for<0, 4>([&](auto i) { sink.template put<A_PE + decltype(i)::value>(vm, pe[decltype(i)::value]); });
-        static_for<0, 2>([&](auto i) { sink.template put<A_VPE + decltype(i)::value>(vm, vpe[decltype(i)::value]); });
+        static_for<0, 4>([&](auto i) { sink.template put<A_PE + decltype(i)::value>(pe[decltype(i)::value]); });
+        static_for<0, 2>([&](auto i) { sink.template put<A_VPE + decltype(i)::value>(vpe[decltype(i)::value]); });
     }
 
     half8 fa[16], fb[16];
@@ -141,28 +191,31 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(FwdArgs a) {
     auto from_a = [&](auto kc) { return fa[decltype(kc)::value]; };
     auto from_b = [&](auto kc) { return fb[decltype(kc)::value]; };
 
+    Pipe pp{st, bias, {}};
     st.start();
-    run_layer<F_L0, 8, 4, BT_L0, true, STORE, A_H0>(st, bias, sink, fa, from_pe);                  // layer 0
-    run_layer<F_L1 + 0 * 128, 8, 16, BT_L1 + 0, true, STORE, A_H0 + 16>(st, bias, sink, fb, from_a);  // layers 1..4
-    run_layer<F_L1 + 1 * 128, 8, 16, BT_L1 + 8, true, STORE, A_H0 + 32>(st, bias, sink, fa, from_b);
-    run_layer<F_L1 + 2 * 128, 8, 16, BT_L1 + 16, true, STORE, A_H0 + 48>(st, bias, sink, fb, from_a);
-    run_layer<F_L1 + 3 * 128, 8, 16, BT_L1 + 24, true, STORE, A_H0 + 64>(st, bias, sink, fa, from_b);
-    run_layer<F_L5, 8, 20, BT_L5, true, STORE, A_H0 + 80>(st, bias, sink, fb, [&](auto kc) {     // layer 5: [PE ; h]
+    pp.acc[0] = load_bias_tile<0>(bias);
+    auto c0 = run_layer<F_L0, 8, 4, BT_L0, true, STORE, A_H0>(pp, sink, fa, from_pe, NoPrev{});                 // layer 0
+    auto c1 = run_layer<F_L1 + 0 * 128, 8, 16, BT_L1 + 0, true, STORE, A_H0 + 16>(pp, sink, fb, from_a, c0);   // layers 1..4
+    auto c2 = run_layer<F_L1 + 1 * 128, 8, 16, BT_L1 + 8, true, STORE, A_H0 + 32>(pp, sink, fa, from_b, c1);
+    auto c3 = run_layer<F_L1 + 2 * 128, 8, 16, BT_L1 + 16, true, STORE, A_H0 + 48>(pp, sink, fb, from_a, c2);
+    auto c4 = run_layer<F_L1 + 3 * 128, 8, 16, BT_L1 + 24, true, STORE, A_H0 + 64>(pp, sink, fa, from_b, c3);
+    auto c5 = run_layer<F_L5, 8, 20, BT_L5, true, STORE, A_H0 + 80>(pp, sink, fb, [&](auto kc) {               // layer 5: [PE ; h]
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 4) return pe[k]; else return fa[k - 4];
-    });
-    run_layer<F_L6 + 0 * 128, 8, 16, BT_L6 + 0, true, STORE, A_H0 + 96>(st, bias, sink, fa, from_b);   // layers 6, 7
-    run_layer<F_L6 + 1 * 128, 8, 16, BT_L6 + 8, true, STORE, A_H0 + 112>(st, bias, sink, fb, from_a);
+    }, c4);
+    auto c6 = run_layer<F_L6 + 0 * 128, 8, 16, BT_L6 + 0, true, STORE, A_H0 + 96>(pp, sink, fa, from_b, c5);   // layers 6, 7
+    auto c7 = run_layer<F_L6 + 1 * 128, 8, 16, BT_L6 + 8, true, STORE, A_H0 + 112>(pp, sink, fb, from_a, c6);
     // alpha head (row 0 of its tile), then the bottleneck (linear)
-    const f32x16 acc_a = run_tile<F_HEADS, 16, BT_ALPHA>(st, bias, from_b);
-    const float sigma = acc_a[0];
-    run_layer<F_HEADS + 16, 8, 16, BT_BOTT, false, STORE, A_BOTT>(st, bias, sink, fa, from_b);
+    float sigma;
+    run_tile<F_HEADS, 16, BT_ALPHA>(pp, from_b, c7);
+    auto c8 = run_layer<F_HEADS + 16, 8, 16, BT_BOTT, false, STORE, A_BOTT>(pp, sink, fa, from_b, KeepRow0{&sigma});
     // view layer: [bottleneck ; view PE] -> 128, relu
-    run_layer<F_VIEW, 4, 18, BT_VIEW, true, STORE, A_V>(st, bias, sink, fb, [&](auto kc) {
+    auto c9 = run_layer<F_VIEW, 4, 18, BT_VIEW, true, STORE, A_V>(pp, sink, fb, [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 16) return fa[k]; else return vpe[k - 16];
-    });
-    const f32x16 acc_c = run_tile<F_RGB, 8, BT_RGB>(st, bias, from_b);                            // rgb rows 0..2
+    }, c8);
+    run_tile<F_RGB, 8, BT_RGB>(pp, from_b, c9);                                                             // rgb rows 0..2
+    const f32x16& acc_c = pp.acc[BT_RGB & 1];
     if (valid && h == 0) a.raw[p] = make_float4(acc_c[0], acc_c[1], acc_c[2], sigma);
 }
 
