@@ -23,6 +23,7 @@
 // 1.187 MFLOP/point of algorithmic work (2.1 % padding: 63->64, 283->288 inputs, 1->32 and 3->32
 // output rows of the two heads).
 #include "mlp_common.h"
+#include "mlp_layout_wide.h"
 
 namespace nerf {
 
@@ -222,33 +223,14 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(FwdArgs a) {
 static int launch_fwd(const FwdArgs& a, int mode, hipStream_t st, const char* what) {
     const int64_t blocks = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
     if (blocks > 0x7fffffffLL) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: too many points (%lld)", what, (long long)a.M);
-    if (mode == 0 && a.act)
-        mlp_fwd_kernel<0, true><<<(unsigned)blocks, 512, 0, st>>>(a);
-    else if (mode == 0)
-        mlp_fwd_kernel<0, false><<<(unsigned)blocks, 512, 0, st>>>(a);
-    else
-        mlp_fwd_kernel<1, false><<<(unsigned)blocks, 512, 0, st>>>(a);
+    (void)mode;
+    mlp_fwd_kernel<0, true><<<(unsigned)blocks, 512, 0, st>>>(a);
     return check_launch(what);
 }
 
 }  // namespace nerf
 
 using namespace nerf;
-
-NERF_API int nerf_mlp_forward_rays(const void* packed, const float* rays, int width,
-                                   const float* z, int64_t n_rays, int S, float* raw,
-                                   nerf_stream_t stream) {
-    NERF_REQUIRE(packed && rays && z && raw, "nerf_mlp_forward_rays: null pointer");
-    NERF_REQUIRE(width >= 11, "nerf_mlp_forward_rays: ray batch needs view directions (width >= 11, got %d)", width);
-    NERF_REQUIRE(n_rays >= 0 && S > 0, "nerf_mlp_forward_rays: bad size");
-    NERF_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0,
-                 "nerf_mlp_forward_rays: packed and raw must be 16-byte aligned");
-    if (n_rays == 0) return 0;
-    FwdArgs a{};
-    a.packed = (const char*)packed, a.rays = rays, a.z = z, a.width = width;
-    a.raw = (float4*)raw, a.M = n_rays * S, a.S = S;
-    return launch_fwd(a, 0, as_stream(stream), "nerf_mlp_forward_rays");
-}
 
 NERF_API size_t nerf_mlp_act_bytes(int64_t n_points) {
     const int64_t wave_tiles = (n_points + kPointsPerBlock - 1) / kPointsPerBlock * kWavesPerBlock;
@@ -265,20 +247,7 @@ NERF_API int nerf_mlp_forward_train(const void* packed, const float* rays, int w
                  "nerf_mlp_forward_train: packed, raw and act must be 16-byte aligned");
     if (n_rays == 0) return 0;
     FwdArgs a{};
-    a.packed = (const char*)packed, a.rays = rays, a.z = z, a.width = width;
+    a.packed = (const char*)packed + lw::kPackedBytes, a.rays = rays, a.z = z, a.width = width;
     a.raw = (float4*)raw, a.act = (char*)act, a.M = n_rays * S, a.S = S;
     return launch_fwd(a, 0, as_stream(stream), "nerf_mlp_forward_train");
-}
-
-NERF_API int nerf_mlp_forward_pts(const void* packed, const float* pts, const float* viewdirs,
-                                  int64_t n, int S, float* raw, nerf_stream_t stream) {
-    NERF_REQUIRE(packed && pts && viewdirs && raw, "nerf_mlp_forward_pts: null pointer");
-    NERF_REQUIRE(n >= 0 && S > 0, "nerf_mlp_forward_pts: bad size");
-    NERF_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0,
-                 "nerf_mlp_forward_pts: packed and raw must be 16-byte aligned");
-    if (n == 0) return 0;
-    FwdArgs a{};
-    a.packed = (const char*)packed, a.pts = pts, a.viewdirs = viewdirs;
-    a.raw = (float4*)raw, a.M = n * S, a.S = S;
-    return launch_fwd(a, 1, as_stream(stream), "nerf_mlp_forward_pts");
 }

@@ -1,0 +1,298 @@
+// Fused NeRF MLP forward for inference on gfx950: query point -> positional encoding -> 8x256 MLP
+// with the skip after layer 4 -> alpha / bottleneck / view layer / rgb, one kernel, activations
+// resident in registers from the first layer to the last (see mlp_layout_wide.h).
+//
+// Work decomposition.  A workgroup is 8 waves (2 per SIMD); each wave owns 32 query points (two
+// 16-point tiles) for the whole network, so a workgroup covers 256 points.  A layer is computed
+// one 16-row output tile at a time: one A fragment per k-step feeds two v_mfma_f32_16x16x32_f16
+// (one per point tile), 2 x 4 fp32 accumulator registers seeded with the biases.  A finished tile
+// is converted (ReLU folded into the fp16 clamp) in four slices placed between the MFMAs of the
+// FOLLOWING tile, so the matrix pipe never waits behind a block of conversion instructions; two
+// consecutive tiles make one B fragment of the next layer.  Two fragment sets ping-pong between
+// layers.  Live state per wave: 2 sets x 2 point tiles x 8 fragments x 4 registers + the
+// encodings (24) + accumulators (16) + the A-fragment pipeline.
+//
+// Weight stream: as in mlp_common.h (L2 -> LDS ring of 16 KiB chunks shared by the 8 waves,
+// counted waits, one barrier per chunk executed half a chunk early).
+//
+// Bound: MFMA.  2344 MFMAs of 16 cycles per 32 points = 1.200 MFLOP/point issued for 1.187
+// MFLOP/point of algorithmic work.
+#include "mlp_common.h"
+#include "mlp_layout_wide.h"
+
+namespace nerf {
+
+struct FwdWideArgs {
+    const char* packed;
+    const float* rays;  // MODE 0: [n_rays, width], z [n_rays, S]
+    const float* z;
+    int width;
+    const float* pts;       // MODE 1: [M,3]
+    const float* viewdirs;  // MODE 1: [M/S,3]
+    float4* raw;            // [M] (r,g,b,sigma)
+    int64_t M;              // points
+    int S;                  // points per ray
+};
+
+constexpr int kWRing = 8;   // LDS ring slots (16 KiB each)
+constexpr int kWDepth = 6;  // chunks in flight ahead of the chunk being synchronised
+using WideStream = Stream<lw::kChunks, kWRing, kWDepth>;
+constexpr int kWRingBytes = WideStream::kRingBytes;
+
+DEV f32x4 mfma_wide(half8 a, half8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+struct WidePipe {
+    WideStream& st;
+    const char* bias;   // bias table in LDS, already offset by this lane group's 16 bytes
+    f32x4 acc[2][2];    // [tile parity][point tile]
+};
+
+// What happens to a finished pair of accumulators (one output tile, both point tiles): four
+// slices, each two registers of one point tile -> one packed dword.
+struct WNoPrev {
+    static constexpr bool kActive = false;
+    template <int S> DEV void slice(const f32x4 (&)[2]) const {}
+};
+// Tile number TL inside its layer: tiles 2s, 2s+1 fill the low / high half of fragment s.
+template <bool RELU, int TL>
+struct WToFrag {
+    static constexpr bool kActive = true;
+    half8* dst0;  // fragment array of point tile 0, point tile 1 follows at +kStride
+    static constexpr int kStride = 8;
+    template <int S> DEV void slice(const f32x4 (&v)[2]) const {
+        constexpr int pt = S >> 1, q = S & 1;
+        const float lo = RELU ? 0.f : -65504.f;
+        const f32x2 x = {__builtin_amdgcn_fmed3f(v[pt][2 * q], lo, 65504.f),
+                         __builtin_amdgcn_fmed3f(v[pt][2 * q + 1], lo, 65504.f)};
+        const half2v p = __builtin_convertvector(x, half2v);
+        half8& f = dst0[pt * kStride + (TL >> 1)];
+        constexpr int e = 4 * (TL & 1) + 2 * q;
+        f[e] = p[0], f[e + 1] = p[1];
+    }
+};
+struct WKeepRow0 {
+    static constexpr bool kActive = true;
+    float* out;  // [2]
+    template <int S> DEV void slice(const f32x4 (&v)[2]) const {
+        if constexpr ((S & 1) == 0) out[S >> 1] = v[S >> 1][0];
+    }
+};
+
+constexpr int w_first_slice_step(int nk) { return nk >= 2 ? 1 : 0; }
+constexpr int w_slices_per_step(int nk) { return nk >= 8 ? 1 : nk >= 4 ? 2 : 4; }
+constexpr int w_last_slice_step(int nk) { return w_first_slice_step(nk) + 3 / w_slices_per_step(nk); }
+constexpr int w_bias_step(int nk) { return w_last_slice_step(nk) > nk - 3 ? w_last_slice_step(nk) : nk - 3; }
+static_assert(w_last_slice_step(2) < 2 && w_last_slice_step(4) < 4 && w_last_slice_step(8) < 8, "slice schedule");
+
+// Output tile T (= its bias tile): NK k-steps of fragments F0..; getB(pt, k) is the B fragment of
+// point tile pt.  Every k-step is one scheduling region: two MFMAs, the LDS read of the A
+// fragment kPrefetch steps ahead, a slice of the previous tile and, late in the tile, the bias
+// seed of the next one.
+template <int F0, int NK, int T, class GetB, class Prev>
+DEV void wide_tile(WidePipe& p, GetB&& getB, const Prev& prev) {
+    static_for<0, NK>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const half8 a = p.st.template take<F0 + k>();
+        p.acc[T & 1][0] = mfma_wide(a, getB(std::integral_constant<int, 0>{}, kc), p.acc[T & 1][0]);
+        p.acc[T & 1][1] = mfma_wide(a, getB(std::integral_constant<int, 1>{}, kc), p.acc[T & 1][1]);
+        if constexpr (Prev::kActive && k >= w_first_slice_step(NK)) {
+            constexpr int sp = w_slices_per_step(NK), s0 = (k - w_first_slice_step(NK)) * sp;
+            static_for<(s0 < 4 ? s0 : 4), (s0 + sp < 4 ? s0 + sp : 4)>(
+                [&](auto sc) { prev.template slice<decltype(sc)::value>(p.acc[(T & 1) ^ 1]); });
+        }
+        if constexpr (k == w_bias_step(NK) && T + 1 < lw::T_END) {
+            const f32x4 b = *(const f32x4*)(p.bias + (T + 1) * 64);
+            p.acc[(T & 1) ^ 1][0] = b;
+            p.acc[(T & 1) ^ 1][1] = b;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// One layer of NT output tiles of NK k-steps; its output becomes fragments 0..NT/2-1 of `out`
+// (both point tiles).  `before` finishes the tile that preceded the layer; the returned object
+// finishes the layer's last tile.
+template <int F0, int NT, int NK, int T0, bool RELU, class GetB, class Prev>
+DEV auto wide_layer(WidePipe& p, half8* out, GetB&& getB, const Prev& before) {
+    wide_tile<F0, NK, T0>(p, getB, before);
+    static_for<1, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        wide_tile<F0 + t * NK, NK, T0 + t>(p, getB, WToFrag<RELU, t - 1>{out});
+    });
+    return WToFrag<RELU, NT - 1>{out};
+}
+
+// Local encoding slots of lane group g for a point: see lw::pe_feature.
+DEV void encode_point(const float (&x)[3], int g, half8 (&out)[2]) {
+    const float e = g == 0 ? x[0] : g == 1 ? x[1] : g == 2 ? x[2] : 0.f;
+    const float base = g == 0 ? 1.f : g == 1 ? 4.f : g == 2 ? 32.f : 128.f;
+    const bool odd = g & 1;
+    float f[3], s[3][3], c[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) f[d] = to_revolutions(x[d] * base);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            s[o][d] = __builtin_amdgcn_sinf(f[d]);
+            c[o][d] = __builtin_amdgcn_cosf(f[d]);
+            if (o < 2) f[d] = double_revolutions(f[d]);
+        }
+    }
+    float v[16];
+    v[0] = e;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        v[1 + d] = odd ? c[0][d] : s[0][d];
+        v[4 + d] = odd ? s[1][d] : c[0][d];
+        v[7 + d] = odd ? c[1][d] : s[1][d];
+        v[10 + d] = odd ? s[2][d] : c[1][d];
+        v[13 + d] = odd ? c[2][d] : s[2][d];
+    }
+    pack_slots<16>(v, out);
+}
+
+// Local view-direction slots of lane group g: see lw::view_feature.
+DEV void encode_view(const float (&x)[3], int g, half8 (&out)[1]) {
+    const float e = g == 0 ? x[0] : g == 1 ? x[1] : g == 2 ? x[2] : 0.f;
+    const float base = g == 0 ? 1.f : g == 1 ? 2.f : g == 2 ? 4.f : 8.f;
+    float v[8];
+    v[0] = e, v[7] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float f = to_revolutions(x[d] * base);
+        v[1 + d] = __builtin_amdgcn_sinf(f);
+        v[4 + d] = __builtin_amdgcn_cosf(f);
+    }
+    pack_slots<8>(v, out);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[kWRingBytes + lw::kBiasBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+
+    VmQueue vm;
+    WideStream st(vm, a.packed, lds, wave, lane);
+    // biases first (oldest in the queue), 1 KiB per wave-load, then the first chunks
+    for (int blk = wave; blk < lw::kBiasBytes / kFragBytes; blk += kWavesPerBlock)
+        glds16_untracked(a.packed + lw::kBiasOffset + blk * kFragBytes + lane * 16,
+                         lds + kWRingBytes + blk * kFragBytes);
+    st.prologue();
+
+    // ---- this lane's two query points (one per point tile) and their view directions ----
+    constexpr int kS = 8;  // fragments (k-steps of 32 features) per point tile in a set
+    half8 fa[2 * kS], fb[2 * kS], pe[2][2], vpe[2][1];
+    int64_t pidx[2];
+    bool valid[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (lane & 15);
+        pidx[pt] = p;
+        valid[pt] = p < a.M;
+        const int64_t pc = valid[pt] ? p : a.M - 1;
+        const int64_t ray = pc / a.S;
+        float x[3], vd[3];
+        if (MODE == 0) {
+            const float* r = a.rays + ray * a.width;
+            const float zz = a.z[pc];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[c] = r[c] + r[3 + c] * zz;  // pts = rays_o + rays_d * z
+                vd[c] = r[8 + c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[c] = a.pts[pc * 3 + c];
+                vd[c] = a.viewdirs[ray * 3 + c];
+            }
+        }
+        encode_point(x, g, pe[pt]);
+        encode_view(vd, g, vpe[pt]);
+    }
+
+    auto from_pe = [&](auto pt, auto kc) { return pe[decltype(pt)::value][decltype(kc)::value]; };
+    auto from_a = [&](auto pt, auto kc) { return fa[decltype(pt)::value * kS + decltype(kc)::value]; };
+    auto from_b = [&](auto pt, auto kc) { return fb[decltype(pt)::value * kS + decltype(kc)::value]; };
+    static_assert(WToFrag<true, 0>::kStride == kS, "fragment set stride");
+
+    WidePipe pp{st, lds + kWRingBytes + g * 16, {}};
+    st.start();
+    {
+        const f32x4 b = *(const f32x4*)(pp.bias);
+        pp.acc[0][0] = b, pp.acc[0][1] = b;
+    }
+    auto c0 = wide_layer<lw::F_L0, 16, 2, lw::T_L0, true>(pp, fa, from_pe, WNoPrev{});                    // layer 0
+    auto c1 = wide_layer<lw::F_L1 + 0 * 128, 16, 8, lw::T_L1 + 0, true>(pp, fb, from_a, c0);             // layers 1..4
+    auto c2 = wide_layer<lw::F_L1 + 1 * 128, 16, 8, lw::T_L1 + 16, true>(pp, fa, from_b, c1);
+    auto c3 = wide_layer<lw::F_L1 + 2 * 128, 16, 8, lw::T_L1 + 32, true>(pp, fb, from_a, c2);
+    auto c4 = wide_layer<lw::F_L1 + 3 * 128, 16, 8, lw::T_L1 + 48, true>(pp, fa, from_b, c3);
+    auto c5 = wide_layer<lw::F_L5, 16, 10, lw::T_L5, true>(pp, fb, [&](auto pt, auto kc) {               // layer 5: [PE ; h]
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < 2) return pe[decltype(pt)::value][k]; else return fa[decltype(pt)::value * kS + k - 2];
+    }, c4);
+    auto c6 = wide_layer<lw::F_L6 + 0 * 128, 16, 8, lw::T_L6 + 0, true>(pp, fa, from_b, c5);             // layers 6, 7
+    auto c7 = wide_layer<lw::F_L6 + 1 * 128, 16, 8, lw::T_L6 + 16, true>(pp, fb, from_a, c6);
+    // alpha head (row 0 of its tile), then the bottleneck (linear)
+    float sigma[2];
+    wide_tile<lw::F_ALPHA, 8, lw::T_ALPHA>(pp, from_b, c7);
+    auto c8 = wide_layer<lw::F_BOTT, 16, 8, lw::T_BOTT, false>(pp, fa, from_b, WKeepRow0{sigma});
+    // view layer: [bottleneck ; view PE] -> 128, relu
+    auto c9 = wide_layer<lw::F_VIEW, 8, 9, lw::T_VIEW, true>(pp, fb, [&](auto pt, auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < 8) return fa[decltype(pt)::value * kS + k]; else return vpe[decltype(pt)::value][0];
+    }, c8);
+    wide_tile<lw::F_RGB, 4, lw::T_RGB>(pp, from_b, c9);                                                  // rgb rows 0..2
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const f32x4& c = pp.acc[lw::T_RGB & 1][pt];
+        if (valid[pt] && g == 0) a.raw[pidx[pt]] = make_float4(c[0], c[1], c[2], sigma[pt]);
+    }
+}
+
+static int launch_fwd_wide(const FwdWideArgs& a, int mode, hipStream_t st, const char* what) {
+    const int64_t blocks = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
+    if (blocks > 0x7fffffffLL) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: too many points (%lld)", what, (long long)a.M);
+    if (mode == 0)
+        mlp_fwd_wide_kernel<0><<<(unsigned)blocks, 512, 0, st>>>(a);
+    else
+        mlp_fwd_wide_kernel<1><<<(unsigned)blocks, 512, 0, st>>>(a);
+    return check_launch(what);
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+NERF_API int nerf_mlp_forward_rays(const void* packed, const float* rays, int width,
+                                   const float* z, int64_t n_rays, int S, float* raw,
+                                   nerf_stream_t stream) {
+    NERF_REQUIRE(packed && rays && z && raw, "nerf_mlp_forward_rays: null pointer");
+    NERF_REQUIRE(width >= 11, "nerf_mlp_forward_rays: ray batch needs view directions (width >= 11, got %d)", width);
+    NERF_REQUIRE(n_rays >= 0 && S > 0, "nerf_mlp_forward_rays: bad size");
+    NERF_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0,
+                 "nerf_mlp_forward_rays: packed and raw must be 16-byte aligned");
+    if (n_rays == 0) return 0;
+    FwdWideArgs a{};
+    a.packed = (const char*)packed, a.rays = rays, a.z = z, a.width = width;
+    a.raw = (float4*)raw, a.M = n_rays * S, a.S = S;
+    return launch_fwd_wide(a, 0, as_stream(stream), "nerf_mlp_forward_rays");
+}
+
+NERF_API int nerf_mlp_forward_pts(const void* packed, const float* pts, const float* viewdirs,
+                                  int64_t n, int S, float* raw, nerf_stream_t stream) {
+    NERF_REQUIRE(packed && pts && viewdirs && raw, "nerf_mlp_forward_pts: null pointer");
+    NERF_REQUIRE(n >= 0 && S > 0, "nerf_mlp_forward_pts: bad size");
+    NERF_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0,
+                 "nerf_mlp_forward_pts: packed and raw must be 16-byte aligned");
+    if (n == 0) return 0;
+    FwdWideArgs a{};
+    a.packed = (const char*)packed, a.pts = pts, a.viewdirs = viewdirs;
+    a.raw = (float4*)raw, a.M = n * S, a.S = S;
+    return launch_fwd_wide(a, 1, as_stream(stream), "nerf_mlp_forward_pts");
+}

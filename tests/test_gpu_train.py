@@ -61,7 +61,8 @@ def test_forward_train_matches_inference_and_saves_activations(gpu):
     act = torch.zeros((ops.act_bytes(9 * 64),), dtype=torch.uint8, device=gpu)
     raw_t = ops.mlp_forward_train(m.packed(), rays, z, act)
     raw_i = ops.mlp_forward_rays(m.packed(), rays, z)
-    assert torch.equal(raw_t, raw_i)
+    # the two kernels tile the same fp16 products differently (fp32 summation order, octave seeds)
+    assert float((raw_t - raw_i).abs().max()) <= 2e-3 * max(1.0, float(raw_i.abs().max()))
     # decode the saved h7 of the first wave tile (points 0..31) and compare with the oracle
     blk = act.view(-1, 158, 1024)[0]
     h7 = blk[4 + 16 * 7: 4 + 16 * 8].contiguous().view(torch.float16).view(16, 64, 8).float().cpu().numpy()
