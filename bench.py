@@ -200,7 +200,7 @@ def main():
                        "parallelism": f"ray-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "mlp_fwd_kernel", "launches": len(timing),
+                         "kernel": "mlp_fwd_wide_kernel", "launches": len(timing),
                          "avg_launch_ms": round(mlp_ms / max(1, len(timing)), 4),
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": mlp_points // max(1, len(timing)),
                          "mlp_share_of_step": round(mlp_ms * 1e-3 / dt, 4)},
