@@ -211,9 +211,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
 // ---------------------------------------------------------------------------------------------
 // 2. weight gradients
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxInTiles = 9;    // 8 tiles of a 256-wide input + 1 (ones column for the bias)
-constexpr int kMaxXBlocks = 16, kMaxYBlocks = 16;
-constexpr int kDwStageBytes = (kMaxXBlocks + kMaxYBlocks) * kFragBytes;  // 36 KiB
+constexpr int kDwStageBytes = 40 * kFragBytes;  // one ring stage: a group of wave tiles of one job
 constexpr int kDwStages = 4;
 constexpr int kNumJobs = 14;  // layers 5 and 9 have two input segments: one job each
 
@@ -233,6 +231,9 @@ struct DwArgs {
     float* gperm;        // [tiles][16 regs][64 lanes]
     int64_t wave_tiles;
     DwJob job[kNumJobs];
+#ifdef DW_STAMPS
+    unsigned long long* stamps;
+#endif
 };
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -264,75 +265,130 @@ DEV half8 tr_operand(const char* img, int kp, int lane, bool one_block) {
     return __builtin_bit_cast(half8, v);
 }
 
-// One workgroup's share of a job with NX input tiles (+ the ones tile when BIAS).
-template <int NX, int BIAS>
+// One workgroup's share of a job with NX input tiles (+ the ones tile when BIAS) and NY gradient
+// tiles per wave tile.  G wave tiles form one ring stage (one barrier, one counted wait), chosen
+// so that a stage is 30-40 KiB whatever the job: a workgroup then always has ~100 KiB of loads
+// in flight, which is what keeps the narrow jobs (rgb, alpha, encoding rows) off the latency
+// bound.  The loads of a stage are dealt round-robin to the 8 waves and padded with repeats to
+// the same count kMine for every wave, so the vmcnt bookkeeping is a compile-time constant.
+//
+// ROW: the job has one output tile (alpha, rgb).  Giving it to one wave would leave that wave
+// alone with every MFMA of the job, so the waves split the INPUT tiles instead: wave w
+// accumulates the product with input tile w (wave 0 also takes the ones tile).
+template <int NX, int NY, int BIAS, int G, bool ROW = false>
 DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave) {
     constexpr int NI = NX + BIAS;
+    static_assert(!ROW || (NY == 1 && NX <= kWavesPerBlock), "row jobs: one gradient tile, one input tile per wave");
+    constexpr int kTileUnits = 2 * (NX + NY);                  // 1 KiB loads per wave tile
+    constexpr int kUnits = kTileUnits * G;                     // per stage
+    constexpr int kMine = (kUnits + kWavesPerBlock - 1) / kWavesPerBlock;
+    constexpr int kTileBytes = kTileUnits * kFragBytes;
+    static_assert(kTileBytes * G <= kDwStageBytes, "stage size");
     const int slice = blockIdx.x - jb.wg0;
     const int64_t per = (a.wave_tiles + jb.wgs - 1) / jb.wgs;
     const int64_t t_lo = slice * per, t_hi = (t_lo + per < a.wave_tiles) ? t_lo + per : a.wave_tiles;
     const bool y_one = jb.y_k == 1;
-    const int ny = (jb.y_k + 1) / 2;        // gradient tiles
-    const int nunit = 2 * (NX + ny);        // 1 KiB loads per staged wave tile
+    const int64_t ntile = t_hi - t_lo;
+    const int64_t nstage = (ntile + G - 1) / G;
 
-    // stage one wave tile: loads are dealt round-robin to the 8 waves
-    auto stage_in = [&](int64_t wt, int sbuf) {
+    // stage a group of wave tiles (a tile index past the end re-loads the last tile: the loads
+    // stay in bounds and the count per wave stays kMine)
+    auto stage_in = [&](int64_t group, int sbuf) {
         char* dst = lds + sbuf * kDwStageBytes;
-        const char* ab = a.act + ((size_t)wt * kActBlocks + jb.x0_blk) * kFragBytes;
-        const char* gb = a.gbuf + ((size_t)wt * kGradBlocks + jb.y_blk) * kFragBytes;
-        for (int u = wave; u < nunit; u += kWavesPerBlock) {
-            const int img = u >> 1;
-            if (img < NX) stage_tile(ab + (size_t)img * kTileImgBytes, dst + img * kTileImgBytes, u & 1, lane, false);
-            else stage_tile(gb + (size_t)(img - NX) * kTileImgBytes, dst + img * kTileImgBytes, u & 1, lane, y_one);
+#pragma unroll
+        for (int m = 0; m < kMine; ++m) {
+            int u = wave + m * kWavesPerBlock;
+            if (u >= kUnits) u -= kUnits;
+            const int gt = u / kTileUnits, r = u % kTileUnits, img = r >> 1;
+            int64_t wt = t_lo + group * G + gt;
+            if (wt >= t_hi) wt = t_hi - 1;
+            char* timg = dst + gt * kTileBytes + img * kTileImgBytes;
+            if (img < NX)
+                stage_tile(a.act + ((size_t)wt * kActBlocks + jb.x0_blk) * kFragBytes + (size_t)img * kTileImgBytes,
+                           timg, r & 1, lane, false);
+            else
+                stage_tile(a.gbuf + ((size_t)wt * kGradBlocks + jb.y_blk) * kFragBytes + (size_t)(img - NX) * kTileImgBytes,
+                           timg, r & 1, lane, y_one);
         }
     };
 
-    f32x16 acc[NI];
+    constexpr int NACC = ROW ? 2 : NI;
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NACC; ++i)
         acc[i] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // constant operand of the ones column: input slot 0 is 1 for every point
     half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((lane & 31) == 0) ones = half8{1, 1, 1, 1, 1, 1, 1, 1};
 
-    const int64_t ntile = t_hi - t_lo;
-    // every staged tile costs this wave the same number of loads
-    const int mine = (nunit - wave + kWavesPerBlock - 1) / kWavesPerBlock;
-    constexpr int kAhead = kDwStages - 1;  // wave tiles in flight beyond the one being consumed
+    constexpr int kAhead = kDwStages - 1;  // stages in flight beyond the one being consumed
 #pragma unroll
     for (int k = 0; k < kAhead; ++k)
-        if (k < ntile) stage_in(t_lo + k, k);
+        if (k < nstage) stage_in(k, k);
     // The stage loop is unrolled over the ring so that every LDS address is a compile-time
     // offset: with a run-time buffer index the compiler cannot tell the transposing reads from
     // the direct-to-LDS loads still in flight and drains the whole queue before every read.
-    for (int64_t it0 = 0; it0 < ntile; it0 += kDwStages) {
+    for (int64_t it0 = 0; it0 < nstage; it0 += kDwStages) {
         static_for<0, kDwStages>([&](auto sc) {
             constexpr int buf = decltype(sc)::value;
             const int64_t it = it0 + buf;
-            if (it < ntile) {
-                // everything but the loads of the tiles after this one has landed
-                const int64_t later = (ntile - 1 - it < kAhead - 1) ? ntile - 1 - it : kAhead - 1;
-                wait_vmcnt_n((int)later * mine);
+            if (it < nstage) {
+                // everything but the loads of the stages after this one has landed
+                const int64_t left = nstage - 1 - it;
+                if (left >= kAhead - 1) wait_vmcnt_n((kAhead - 1) * kMine);
+                else if (left == 1) wait_vmcnt_n(kMine);
+                else wait_vmcnt_n(0);
                 asm volatile("s_barrier" ::: "memory");
                 // the buffer read in the previous iteration is free again (every wave passed the barrier)
                 constexpr int nbuf = (buf + kAhead) % kDwStages;
-                if (it + kAhead < ntile) stage_in(t_lo + it + kAhead, nbuf);
-                if (wave < jb.n_out) {
-                    const char* stage = lds + buf * kDwStageBytes;
+                if (it + kAhead < nstage) stage_in(it + kAhead, nbuf);
+                if constexpr (ROW) {
+                    if (wave < NX) {
 #pragma unroll
-                    for (int kp = 0; kp < 2; ++kp) {
-                        const half8 ya = tr_operand(stage + (NX + wave) * kTileImgBytes, kp, lane, y_one);
+                        for (int gt = 0; gt < G; ++gt) {
+                            if (it * G + gt < ntile) {
+                                const char* stage = lds + buf * kDwStageBytes + gt * kTileBytes;
 #pragma unroll
-                        for (int i = 0; i < NX; ++i)
-                            acc[i] = mfma(ya, tr_operand(stage + i * kTileImgBytes, kp, lane, false), acc[i]);
-                        if constexpr (BIAS) acc[NX] = mfma(ya, ones, acc[NX]);
+                                for (int kp = 0; kp < 2; ++kp) {
+                                    const half8 ya = tr_operand(stage + NX * kTileImgBytes, kp, lane, y_one);
+                                    acc[0] = mfma(ya, tr_operand(stage + wave * kTileImgBytes, kp, lane, false), acc[0]);
+                                    if (BIAS && wave == 0) acc[1] = mfma(ya, ones, acc[1]);
+                                }
+                            }
+                        }
+                    }
+                } else if (wave < jb.n_out) {
+#pragma unroll
+                    for (int gt = 0; gt < G; ++gt) {
+                        if (it * G + gt < ntile) {
+                            const char* stage = lds + buf * kDwStageBytes + gt * kTileBytes;
+#pragma unroll
+                            for (int kp = 0; kp < 2; ++kp) {
+                                const half8 ya = tr_operand(stage + (NX + wave) * kTileImgBytes, kp, lane, y_one);
+#pragma unroll
+                                for (int i = 0; i < NX; ++i)
+                                    acc[i] = mfma(ya, tr_operand(stage + i * kTileImgBytes, kp, lane, false), acc[i]);
+                                if constexpr (BIAS) acc[NX] = mfma(ya, ones, acc[NX]);
+                            }
+                        }
                     }
                 }
             }
         });
     }
     // add this workgroup's partial dW^T to the global buffer (256 contiguous bytes per register)
-    if (wave < jb.n_out && ntile > 0) {
+    if constexpr (ROW) {
+        if (wave < NX && ntile > 0) {
+            float* dst = a.gperm + ((size_t)(jb.tile0 + wave) * 16) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, acc[0][r]);
+            if (BIAS && wave == 0) {
+                dst = a.gperm + ((size_t)(jb.tile0 + NX) * 16) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, acc[1][r]);
+            }
+        }
+    } else if (wave < jb.n_out && ntile > 0) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             float* dst = a.gperm + ((size_t)(jb.tile0 + wave * NI + i) * 16) * 64 + lane;
@@ -351,12 +407,19 @@ __global__ __launch_bounds__(512) void mlp_dw_kernel(DwArgs a) {
     for (int j = 1; j < kNumJobs; ++j)
         if ((int)blockIdx.x >= a.job[j].wg0) ji = j;
     const DwJob jb = a.job[ji];
-    const int nx = jb.x0_k / 2;
-    if (nx == 8 && jb.bias) dw_body<8, 1>(a, jb, lds, lane, wave);
-    else if (nx == 8) dw_body<8, 0>(a, jb, lds, lane, wave);
-    else if (nx == 2) dw_body<2, 1>(a, jb, lds, lane, wave);
-    else if (nx == 4) dw_body<4, 1>(a, jb, lds, lane, wave);
-    else dw_body<1, 0>(a, jb, lds, lane, wave);
+    const int nx = jb.x0_k / 2, ny = (jb.y_k + 1) / 2;
+#ifdef DW_STAMPS
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    struct Stamp { unsigned long long* p; unsigned long long t0; int j;
+        __device__ ~Stamp() { if (threadIdx.x == 0) { p[3 * blockIdx.x] = t0; p[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); p[3 * blockIdx.x + 2] = j; } } } stamp{a.stamps, t_begin, ji};
+#endif
+    if (nx == 8 && ny == 8 && jb.bias) dw_body<8, 8, 1, 1>(a, jb, lds, lane, wave);       // hidden layers, bottleneck
+    else if (nx == 8 && ny == 8) dw_body<8, 8, 0, 1>(a, jb, lds, lane, wave);            // layer 5, h4 rows
+    else if (nx == 2) dw_body<2, 8, 1, 2>(a, jb, lds, lane, wave);                       // encoding rows of layers 0, 5
+    else if (nx == 8 && ny == 1) dw_body<8, 1, 1, 2, true>(a, jb, lds, lane, wave);      // alpha
+    else if (nx == 8) dw_body<8, 4, 1, 1>(a, jb, lds, lane, wave);                       // view layer, bottleneck rows
+    else if (nx == 4) dw_body<4, 1, 1, 3, true>(a, jb, lds, lane, wave);                 // rgb
+    else dw_body<1, 4, 0, 3>(a, jb, lds, lane, wave);                                    // view layer, view-encoding rows
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,6 +530,11 @@ static int gperm_tiles() {
 
 using namespace nerf;
 
+#ifdef DW_STAMPS
+unsigned long long* g_dw_stamps = nullptr;
+NERF_API void nerf_debug_set_stamps(void* p) { g_dw_stamps = (unsigned long long*)p; }
+#endif
+
 NERF_API size_t nerf_mlp_packed_bwd_bytes(void) { return layout::kPackedBwdBytes; }
 
 NERF_API int nerf_mlp_pack_bwd(const float* const* params, void* packed_bwd, nerf_stream_t stream) {
@@ -514,6 +582,9 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     hipError_t e = hipMemsetAsync(partial, 0, (size_t)tiles * 16 * 64 * sizeof(float), st);
     if (e != hipSuccess) return NERF_FAIL((int)e, "nerf_mlp_backward(memset): %s", hipGetErrorString(e));
     const int total_wgs = da.job[kNumJobs - 1].wg0 + da.job[kNumJobs - 1].wgs;
+#ifdef DW_STAMPS
+    da.stamps = g_dw_stamps;
+#endif
     mlp_dw_kernel<<<total_wgs, 512, 0, st>>>(da);
     rc = check_launch("nerf_mlp_backward(dw)");
     if (rc) return rc;
