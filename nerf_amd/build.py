@@ -52,7 +52,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + os.environ.get("NERF_HIP_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")

@@ -52,6 +52,10 @@ struct ActSink {
     DEV void put(const half8& v) const {
         *(half8*)(base + BLK * kFragBytes) = v;  // stores are not counted: see VmQueue
     }
+    template <int BLK, class V>
+    DEV void put_mask(const V& v) const {
+        *(V*)(base + BLK * kFragBytes) = v;
+    }
 };
 
 // What happens to a finished accumulator tile.  The work is cut into eight slices that run
@@ -62,12 +66,16 @@ struct NoPrev {
     template <int S> DEV void slice(const f32x16&) const {}
 };
 // Registers 2S, 2S+1 -> packed dword S&3 of fragment S>>2: round to nearest even, clamped to the
-// fp16 range; RELU folds the activation into the clamp (one v_med3_f32).
-template <bool RELU, bool STORE, int BLK>
+// fp16 range; RELU folds the activation into the clamp (one v_med3_f32).  When STORE, finished
+// fragments go to blocks BLK, BLK+1 of the saved activations and, for MBLK >= 0, the layer's ReLU
+// mask bits (tile TL of NT) are collected in mk[] and stored as block MBLK after the last tile.
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+template <bool RELU, bool STORE, int BLK, int TL = 0, int NT = 0, int MBLK = -1>
 struct ToFrags {
     static constexpr bool kActive = true;
     half8* dst;
     ActSink sink;
+    unsigned* mk;
     template <int S> DEV void slice(const f32x16& v) const {
         const float lo = RELU ? 0.f : -65504.f;
         const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * S], lo, 65504.f),
@@ -76,6 +84,14 @@ struct ToFrags {
         half8& f = dst[S >> 2];
         f[2 * (S & 3)] = p[0], f[2 * (S & 3) + 1] = p[1];
         if constexpr (STORE && (S & 3) == 3) sink.template put<BLK + (S >> 2)>(f);
+        if constexpr (STORE && MBLK >= 0) {
+            const unsigned pw = __builtin_bit_cast(unsigned, p);
+            const unsigned bits = ((pw & 0xFFFFu) ? 1u : 0u) | ((pw >> 16) ? 2u : 0u);
+            constexpr int sh = 16 * (TL & 1) + 2 * S;
+            if constexpr (sh == 0) mk[TL >> 1] = bits; else mk[TL >> 1] |= bits << sh;
+            if constexpr (TL == NT - 1 && S == 7)
+                sink.template put_mask<MBLK>(uint4v{mk[0], NT > 2 ? mk[1] : 0u, NT > 4 ? mk[2] : 0u, NT > 6 ? mk[3] : 0u});
+        }
     }
 };
 struct KeepRow0 {
@@ -122,14 +138,15 @@ DEV void run_tile(Pipe& p, GetB&& getB, const Prev& prev) {
 // One layer of NT output tiles; tile t becomes fragments 2t, 2t+1 of `out` (and, when STORE,
 // blocks ABLK + 2t, ABLK + 2t + 1 of the saved activations).  `before` finishes the tile that
 // preceded the layer; the returned object finishes the layer's last tile.
-template <int F0, int NT, int NK, int T0, bool RELU, bool STORE, int ABLK, class GetB, class Prev>
-DEV auto run_layer(Pipe& p, const ActSink& sink, half8* out, GetB&& getB, const Prev& before) {
+template <int F0, int NT, int NK, int T0, bool RELU, bool STORE, int ABLK, int MBLK, class GetB, class Prev>
+DEV auto run_layer(Pipe& p, const ActSink& sink, unsigned* mk, half8* out, GetB&& getB, const Prev& before) {
     run_tile<F0, NK, T0>(p, getB, before);
     static_for<1, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        run_tile<F0 + t * NK, NK, T0 + t>(p, getB, ToFrags<RELU, STORE, ABLK + 2 * (t - 1)>{out + 2 * (t - 1), sink});
+        run_tile<F0 + t * NK, NK, T0 + t>(
+            p, getB, ToFrags<RELU, STORE, ABLK + 2 * (t - 1), t - 1, NT, MBLK>{out + 2 * (t - 1), sink, mk});
     });
-    return ToFrags<RELU, STORE, ABLK + 2 * (NT - 1)>{out + 2 * (NT - 1), sink};
+    return ToFrags<RELU, STORE, ABLK + 2 * (NT - 1), NT - 1, NT, MBLK>{out + 2 * (NT - 1), sink, mk};
 }
 
 template <int MODE, bool STORE>
@@ -193,25 +210,26 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(FwdArgs a) {
     auto from_b = [&](auto kc) { return fb[decltype(kc)::value]; };
 
     Pipe pp{st, bias, {}};
+    unsigned mk[4] = {0u, 0u, 0u, 0u};
     st.start();
     pp.acc[0] = load_bias_tile<0>(bias);
-    auto c0 = run_layer<F_L0, 8, 4, BT_L0, true, STORE, A_H0>(pp, sink, fa, from_pe, NoPrev{});                 // layer 0
-    auto c1 = run_layer<F_L1 + 0 * 128, 8, 16, BT_L1 + 0, true, STORE, A_H0 + 16>(pp, sink, fb, from_a, c0);   // layers 1..4
-    auto c2 = run_layer<F_L1 + 1 * 128, 8, 16, BT_L1 + 8, true, STORE, A_H0 + 32>(pp, sink, fa, from_b, c1);
-    auto c3 = run_layer<F_L1 + 2 * 128, 8, 16, BT_L1 + 16, true, STORE, A_H0 + 48>(pp, sink, fb, from_a, c2);
-    auto c4 = run_layer<F_L1 + 3 * 128, 8, 16, BT_L1 + 24, true, STORE, A_H0 + 64>(pp, sink, fa, from_b, c3);
-    auto c5 = run_layer<F_L5, 8, 20, BT_L5, true, STORE, A_H0 + 80>(pp, sink, fb, [&](auto kc) {               // layer 5: [PE ; h]
+    auto c0 = run_layer<F_L0, 8, 4, BT_L0, true, STORE, A_H0, A_MASK + 0>(pp, sink, mk, fa, from_pe, NoPrev{});                 // layer 0
+    auto c1 = run_layer<F_L1 + 0 * 128, 8, 16, BT_L1 + 0, true, STORE, A_H0 + 16, A_MASK + 1>(pp, sink, mk, fb, from_a, c0);   // layers 1..4
+    auto c2 = run_layer<F_L1 + 1 * 128, 8, 16, BT_L1 + 8, true, STORE, A_H0 + 32, A_MASK + 2>(pp, sink, mk, fa, from_b, c1);
+    auto c3 = run_layer<F_L1 + 2 * 128, 8, 16, BT_L1 + 16, true, STORE, A_H0 + 48, A_MASK + 3>(pp, sink, mk, fb, from_a, c2);
+    auto c4 = run_layer<F_L1 + 3 * 128, 8, 16, BT_L1 + 24, true, STORE, A_H0 + 64, A_MASK + 4>(pp, sink, mk, fa, from_b, c3);
+    auto c5 = run_layer<F_L5, 8, 20, BT_L5, true, STORE, A_H0 + 80, A_MASK + 5>(pp, sink, mk, fb, [&](auto kc) {               // layer 5: [PE ; h]
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 4) return pe[k]; else return fa[k - 4];
     }, c4);
-    auto c6 = run_layer<F_L6 + 0 * 128, 8, 16, BT_L6 + 0, true, STORE, A_H0 + 96>(pp, sink, fa, from_b, c5);   // layers 6, 7
-    auto c7 = run_layer<F_L6 + 1 * 128, 8, 16, BT_L6 + 8, true, STORE, A_H0 + 112>(pp, sink, fb, from_a, c6);
+    auto c6 = run_layer<F_L6 + 0 * 128, 8, 16, BT_L6 + 0, true, STORE, A_H0 + 96, A_MASK + 6>(pp, sink, mk, fa, from_b, c5);   // layers 6, 7
+    auto c7 = run_layer<F_L6 + 1 * 128, 8, 16, BT_L6 + 8, true, STORE, A_H0 + 112, A_MASK + 7>(pp, sink, mk, fb, from_a, c6);
     // alpha head (row 0 of its tile), then the bottleneck (linear)
     float sigma;
     run_tile<F_HEADS, 16, BT_ALPHA>(pp, from_b, c7);
-    auto c8 = run_layer<F_HEADS + 16, 8, 16, BT_BOTT, false, STORE, A_BOTT>(pp, sink, fa, from_b, KeepRow0{&sigma});
+    auto c8 = run_layer<F_HEADS + 16, 8, 16, BT_BOTT, false, STORE, A_BOTT, -1>(pp, sink, mk, fa, from_b, KeepRow0{&sigma});
     // view layer: [bottleneck ; view PE] -> 128, relu
-    auto c9 = run_layer<F_VIEW, 4, 18, BT_VIEW, true, STORE, A_V>(pp, sink, fb, [&](auto kc) {
+    auto c9 = run_layer<F_VIEW, 4, 18, BT_VIEW, true, STORE, A_V, A_MASK + 8>(pp, sink, mk, fb, [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 16) return fa[k]; else return vpe[k - 16];
     }, c8);

@@ -55,7 +55,10 @@ constexpr int A_H0 = 4;      // 16 blocks per layer output h0..h7 (after ReLU): 
 constexpr int A_BOTT = 132;  // 16 blocks: bottleneck (linear)
 constexpr int A_V = 148;     //  8 blocks: view layer output (after ReLU)
 constexpr int A_VPE = 156;   //  2 blocks: view-direction encoding (32 slots)
-constexpr int kActBlocks = 158;
+constexpr int A_MASK = 158;  //  1 block per layer output h0..h7 and one for v (A_MASK + 8): ReLU masks, one
+                             //  bit per unit: lane (point, half) holds 4 dwords; accumulator tile t of the
+                             //  layer owns halfword t&1 of dword t>>1, bit r = register r of the tile > 0
+constexpr int kActBlocks = 167;
 
 constexpr int G_DV = 0;      //  8 blocks: d(view layer pre-activation)
 constexpr int G_DBOTT = 8;   // 16 blocks: d(bottleneck)

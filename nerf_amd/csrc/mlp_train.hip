@@ -69,61 +69,41 @@ __global__ __launch_bounds__(64) void mlp_pack_bwd_kernel(ParamPtrsB pp, char* _
 // ---------------------------------------------------------------------------------------------
 // 1. gradient chain
 // ---------------------------------------------------------------------------------------------
-constexpr int kBwdRing = 7, kBwdDepth = 5;
+constexpr int kBwdRing = 8, kBwdDepth = 6;
 using BwdStream = Stream<kBwdChunks, kBwdRing, kBwdDepth>;
-constexpr int kMaskDepth = 3;                       // mask tiles in flight per wave
-constexpr int kMaskTiles = 4 + 8 * 8;               // v (4 tiles), h7 .. h0 (8 tiles each)
-constexpr int kMaskBytesPerWave = kMaskDepth * 2 * kFragBytes;
-constexpr int kBwdLds = BwdStream::kRingBytes + kWavesPerBlock * kMaskBytesPerWave;
+constexpr int kBwdLds = BwdStream::kRingBytes;
 static_assert(kBwdLds <= 160 * 1024, "LDS budget");
 
 typedef short short8 __attribute__((ext_vector_type(8)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
-// Block of the saved activations that masks tile M of the chain.
-__host__ __device__ constexpr int mask_block(int M) {
-    return M < 4 ? A_V + 2 * M : A_H0 + 16 * (7 - (M - 4) / 8) + 2 * ((M - 4) % 8);
-}
-
-struct MaskPipe {
-    VmQueue& vm;
-    const char* gact;  // this lane's address in block 0 of its wave tile's activations
-    char* lds;         // this wave's slice
-    int lane_off;
-    int mark[kMaskDepth];
-
-    template <int M>
-    DEV void issue() {
-        const char* g = gact + mask_block(M) * kFragBytes;
-        char* l = lds + (M % kMaskDepth) * 2 * kFragBytes;
-        glds16(g, l);
-        glds16(g + kFragBytes, l + kFragBytes);
-        vm.issued += 2;
-        mark[M % kMaskDepth] = vm.issued;
+// 16-byte load into registers issued from inline asm and counted in the VmQueue like the weight
+// stream's loads (a load the compiler knows about would make it wait for vmcnt(0), i.e. for the
+// whole stream and every pending store, before the first use).
+struct MaskLoad {
+    uint4v v;
+    int mark;
+    DEV void issue(VmQueue& vm, const void* g) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(g) : "memory");
+        vm.issued += 1;
+        mark = vm.issued;
     }
-
-    // The two activation fragments of mask tile M; then refills its slot with tile M + depth.
-    template <int M>
-    DEV void get(half8& m0, half8& m1) {
-        vm.wait_until(mark[M % kMaskDepth]);
-        const char* l = lds + (M % kMaskDepth) * 2 * kFragBytes + lane_off;
-        m0 = *(const half8*)l;
-        m1 = *(const half8*)(l + kFragBytes);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the slot is refilled
-        if constexpr (M + kMaskDepth < kMaskTiles) issue<M + kMaskDepth>();
+    // The loaded value; every use is ordered behind the counted wait.
+    DEV uint4v get(const VmQueue& vm) {
+        vm.wait_until(mark);
+        asm volatile("" : "+v"(v));
+        return v;
     }
 };
-
-DEV half8 mask_by(half8 d, half8 act) {
-    const short8 keep = __builtin_bit_cast(short8, act) != (short8)0;  // -1 where the unit was active
-    return __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, d) & keep));
-}
 
 struct GradSink {
     char* base;
     template <int BLK>
-    DEV void put(VmQueue& vm, const half8& v) const {
+    DEV void put(const half8& v) const {
+#ifdef EXP_NO_GRAD_STORE
+        if (v[0] == (_Float16)12345.f)
+#endif
         *(half8*)(base + BLK * kFragBytes) = v;  // stores are not counted: see VmQueue
-        (void)vm;
     }
 };
 
@@ -136,27 +116,73 @@ struct ChainArgs {
     float gscale;
 };
 
-template <int F0, int NT, int NK, int MASK0, int GBLK, class GetB>
-DEV void bwd_layer(BwdStream& st, MaskPipe& mp, const GradSink& sink, half8* out, GetB&& getB) {
-    static_for<0, NT>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        static_for<0, NK>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            acc = mfma(st.template take<F0 + t * NK + k>(), getB(kc), acc);
-        });
-        half8 d0 = to_frag<0, false>(acc), d1 = to_frag<1, false>(acc);
-        if constexpr (MASK0 >= 0) {
-            half8 m0, m1;
-            mp.template get<MASK0 + t>(m0, m1);
-            d0 = mask_by(d0, m0);
-            d1 = mask_by(d1, m1);
+struct ChainPipe {
+    BwdStream& st;
+    f32x16 acc[2];  // tile t accumulates in acc[t & 1] while tile t-1 is converted out of the other
+};
+
+// What happens to a finished gradient tile: eight slices (two registers -> one packed dword,
+// clamped to the fp16 range, ANDed with the unit's ReLU mask bits) run between the MFMAs of the
+// following tile; finished fragments are stored as blocks GBLK + 2*TL, +1 for the dW kernel.
+struct CNoPrev {
+    static constexpr bool kActive = false;
+    template <int S> DEV void slice(const f32x16&) const {}
+};
+template <bool MASKED, int TL, int GBLK>
+struct CToFrags {
+    static constexpr bool kActive = true;
+    half8* dst;   // the layer's fragment set
+    GradSink sink;
+    uint4v mk;    // the layer's mask bits (see A_MASK in mlp_layout.h)
+    template <int S> DEV void slice(const f32x16& v) const {
+        const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * S], -65504.f, 65504.f),
+                         __builtin_amdgcn_fmed3f(v[2 * S + 1], -65504.f, 65504.f)};
+        half2v p = __builtin_convertvector(x, half2v);
+        if constexpr (MASKED) {
+            constexpr int sh = 16 * (TL & 1) + 2 * S;
+            const unsigned w = mk[TL >> 1] >> sh;
+            const unsigned keep = ((w & 1u) ? 0x0000FFFFu : 0u) | ((w & 2u) ? 0xFFFF0000u : 0u);
+            p = __builtin_bit_cast(half2v, __builtin_bit_cast(unsigned, p) & keep);
         }
-        out[2 * t] = d0;
-        out[2 * t + 1] = d1;
-        sink.template put<GBLK + 2 * t>(st.vm, d0);
-        sink.template put<GBLK + 2 * t + 1>(st.vm, d1);
+        half8& f = dst[2 * TL + (S >> 2)];
+        f[2 * (S & 3)] = p[0], f[2 * (S & 3) + 1] = p[1];
+        if constexpr ((S & 3) == 3) sink.template put<GBLK + 2 * TL + (S >> 2)>(f);
+    }
+};
+
+constexpr int c_first_slice_step(int nk) { return nk >= 10 ? 2 : nk >= 2 ? 1 : 0; }
+constexpr int c_slices_per_step(int nk) { return nk >= 10 ? 1 : nk >= 5 ? 2 : 8; }
+
+// Gradient tile PAR (parity of its number): NK k-steps of fragments F0..; one scheduling region
+// per k-step (MFMA, LDS read of the A fragment kPrefetch steps ahead, slices of the previous tile).
+template <int F0, int NK, int PAR, class GetB, class Prev>
+DEV void chain_tile(ChainPipe& p, GetB&& getB, const Prev& prev) {
+    static_for<0, NK>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const half8 a = p.st.template take<F0 + k>();
+        if constexpr (k == 0)
+            p.acc[PAR] = mfma(a, getB(kc), f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+        else
+            p.acc[PAR] = mfma(a, getB(kc), p.acc[PAR]);
+        if constexpr (Prev::kActive && k >= c_first_slice_step(NK)) {
+            constexpr int sp = c_slices_per_step(NK), s0 = (k - c_first_slice_step(NK)) * sp;
+            static_for<(s0 < 8 ? s0 : 8), (s0 + sp < 8 ? s0 + sp : 8)>(
+                [&](auto sc) { prev.template slice<decltype(sc)::value>(p.acc[PAR ^ 1]); });
+        }
+        __builtin_amdgcn_sched_barrier(0);
     });
+}
+
+// One layer of the chain: NT (even) gradient tiles of NK k-steps into the fragment set `out`.
+template <int F0, int NT, int NK, bool MASKED, int GBLK, class GetB, class Prev>
+DEV auto chain_layer(ChainPipe& p, const GradSink& sink, const uint4v& mk, half8* out, GetB&& getB, const Prev& before) {
+    static_assert(NT % 2 == 0, "tile parity restarts at every layer");
+    chain_tile<F0, NK, 0>(p, getB, before);
+    static_for<1, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        chain_tile<F0 + t * NK, NK, t & 1>(p, getB, CToFrags<MASKED, t - 1, GBLK>{out, sink, mk});
+    });
+    return CToFrags<MASKED, NT - 1, GBLK>{out, sink, mk};
 }
 
 __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
@@ -169,9 +195,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
     VmQueue vm;
     BwdStream st(vm, a.packed_bwd, lds, wave, lane);
     st.prologue();
-    MaskPipe mp{vm, a.act + (size_t)wave_tile * kActBlocks * kFragBytes + lane * 16,
-                lds + BwdStream::kRingBytes + wave * kMaskBytesPerWave, lane * 16, {}};
-    static_for<0, kMaskDepth>([&](auto m) { mp.template issue<decltype(m)::value>(); });
+    const char* masks = a.act + ((size_t)wave_tile * kActBlocks + A_MASK) * kFragBytes + lane * 16;
+    MaskLoad mv, m7, m6, m5, m4, m3, m2, m1, m0;
+    mv.issue(vm, masks + 8 * kFragBytes);
+    m7.issue(vm, masks + 7 * kFragBytes);
     GradSink sink{a.gbuf + (size_t)wave_tile * kGradBlocks * kFragBytes + lane * 16};
 
     const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + (lane & 31);
@@ -185,27 +212,38 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
         dC[2] = (_Float16)__builtin_amdgcn_fmed3f(g.z * a.gscale, -lim, lim);
         dA[0] = (_Float16)__builtin_amdgcn_fmed3f(g.w * a.gscale, -lim, lim);
     }
-    sink.template put<G_DA>(vm, dA);
-    sink.template put<G_DC>(vm, dC);
+    sink.template put<G_DA>(dA);
+    sink.template put<G_DC>(dC);
 
     half8 fa[16], fb[16];
     auto from_a = [&](auto kc) { return fa[decltype(kc)::value]; };
     auto from_b = [&](auto kc) { return fb[decltype(kc)::value]; };
+    const uint4v none = {0u, 0u, 0u, 0u};
 
+    ChainPipe pp{st, {}};
     st.start();
-    bwd_layer<B_V, 4, 1, 0, G_DV>(st, mp, sink, fa, [&](auto) { return dC; });              // d v_pre
-    bwd_layer<B_BOTT, 8, 8, -1, G_DBOTT>(st, mp, sink, fb, from_a);                          // d bott
-    bwd_layer<B_H7, 8, 17, 4, G_DPRE0 + 16 * 7>(st, mp, sink, fa, [&](auto kc) {             // d pre7
+    // each layer's mask bits are requested one layer before they are needed
+    auto c0 = chain_layer<B_V, 4, 1, true, G_DV>(pp, sink, mv.get(vm), fa, [&](auto) { return dC; }, CNoPrev{});   // d v_pre
+    m6.issue(vm, masks + 6 * kFragBytes);
+    auto c1 = chain_layer<B_BOTT, 8, 8, false, G_DBOTT>(pp, sink, none, fb, from_a, c0);                           // d bott
+    auto c2 = chain_layer<B_H7, 8, 17, true, G_DPRE0 + 16 * 7>(pp, sink, m7.get(vm), fa, [&](auto kc) {            // d pre7
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 16) return fb[k]; else return dA;
-    });
-    bwd_layer<B_H6 + 0 * 128, 8, 16, 12, G_DPRE0 + 16 * 6>(st, mp, sink, fb, from_a);        // d pre6
-    bwd_layer<B_H6 + 1 * 128, 8, 16, 20, G_DPRE0 + 16 * 5>(st, mp, sink, fa, from_b);        // d pre5
-    bwd_layer<B_H6 + 2 * 128, 8, 16, 28, G_DPRE0 + 16 * 4>(st, mp, sink, fb, from_a);        // d pre4
-    bwd_layer<B_H6 + 3 * 128, 8, 16, 36, G_DPRE0 + 16 * 3>(st, mp, sink, fa, from_b);        // d pre3
-    bwd_layer<B_H6 + 4 * 128, 8, 16, 44, G_DPRE0 + 16 * 2>(st, mp, sink, fb, from_a);        // d pre2
-    bwd_layer<B_H6 + 5 * 128, 8, 16, 52, G_DPRE0 + 16 * 1>(st, mp, sink, fa, from_b);        // d pre1
-    bwd_layer<B_H6 + 6 * 128, 8, 16, 60, G_DPRE0 + 16 * 0>(st, mp, sink, fb, from_a);        // d pre0
+    }, c1);
+    m5.issue(vm, masks + 5 * kFragBytes);
+    auto c3 = chain_layer<B_H6 + 0 * 128, 8, 16, true, G_DPRE0 + 16 * 6>(pp, sink, m6.get(vm), fb, from_a, c2);    // d pre6
+    m4.issue(vm, masks + 4 * kFragBytes);
+    auto c4 = chain_layer<B_H6 + 1 * 128, 8, 16, true, G_DPRE0 + 16 * 5>(pp, sink, m5.get(vm), fa, from_b, c3);    // d pre5
+    m3.issue(vm, masks + 3 * kFragBytes);
+    auto c5 = chain_layer<B_H6 + 2 * 128, 8, 16, true, G_DPRE0 + 16 * 4>(pp, sink, m4.get(vm), fb, from_a, c4);    // d pre4
+    m2.issue(vm, masks + 2 * kFragBytes);
+    auto c6 = chain_layer<B_H6 + 3 * 128, 8, 16, true, G_DPRE0 + 16 * 3>(pp, sink, m3.get(vm), fa, from_b, c5);    // d pre3
+    m1.issue(vm, masks + 1 * kFragBytes);
+    auto c7 = chain_layer<B_H6 + 4 * 128, 8, 16, true, G_DPRE0 + 16 * 2>(pp, sink, m2.get(vm), fb, from_a, c6);    // d pre2
+    m0.issue(vm, masks + 0 * kFragBytes);
+    auto c8 = chain_layer<B_H6 + 5 * 128, 8, 16, true, G_DPRE0 + 16 * 1>(pp, sink, m1.get(vm), fa, from_b, c7);    // d pre1
+    auto c9 = chain_layer<B_H6 + 6 * 128, 8, 16, true, G_DPRE0 + 16 * 0>(pp, sink, m0.get(vm), fb, from_a, c8);    // d pre0
+    static_for<0, 8>([&](auto sc) { c9.template slice<decltype(sc)::value>(pp.acc[1]); });
 }
 
 // ---------------------------------------------------------------------------------------------

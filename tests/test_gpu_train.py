@@ -64,7 +64,7 @@ def test_forward_train_matches_inference_and_saves_activations(gpu):
     # the two kernels tile the same fp16 products differently (fp32 summation order, octave seeds)
     assert float((raw_t - raw_i).abs().max()) <= 2e-3 * max(1.0, float(raw_i.abs().max()))
     # decode the saved h7 of the first wave tile (points 0..31) and compare with the oracle
-    blk = act.view(-1, 158, 1024)[0]
+    blk = act.view(-1, 167, 1024)[0]
     h7 = blk[4 + 16 * 7: 4 + 16 * 8].contiguous().view(torch.float16).view(16, 64, 8).float().cpu().numpy()
     zz = z.cpu().numpy().astype(np.float64)
     r = rb.astype(np.float64)
@@ -107,8 +107,8 @@ def _mlp_grads_reference(ws, rb, z, d_raw, act):
     must follow the forward pass it belongs to, so the reference takes the on/off pattern from
     the activations the GPU forward saved and differentiates pre * mask instead of relu(pre)."""
     n_points = z.size
-    masks = [torch.tensor(_decode_blocks(act, 158, 4 + 16 * l, 16, n_points) != 0) for l in range(8)]
-    mask_v = torch.tensor(_decode_blocks(act, 158, 148, 8, n_points) != 0)
+    masks = [torch.tensor(_decode_blocks(act, 167, 4 + 16 * l, 16, n_points) != 0) for l in range(8)]
+    mask_v = torch.tensor(_decode_blocks(act, 167, 148, 8, n_points) != 0)
     W = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws]
     r = torch.tensor(rb, dtype=torch.float64)
     zz = torch.tensor(z, dtype=torch.float64)
