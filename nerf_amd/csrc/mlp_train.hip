@@ -474,7 +474,12 @@ struct UnpackArgs {
     int accumulate;
     int tile0[kNumJobs];
     int n_in[kNumJobs];
+    int first[25];  // first flat index of each parameter array (get_weights order); [24] = total
 };
+
+// (inputs, outputs) of the 12 layers in get_weights() order
+__device__ const int kLayerDims[12][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
+                                          {256, 256}, {256, 256}, {256, 256}, {283, 128}, {128, 3}, {256, 1}};
 
 // Slot (tile, row) of feature f of a 256- or 128-wide activation in fragment order.
 __device__ __forceinline__ void acc_slot(int f, int& tile, int& row) {
@@ -498,12 +503,18 @@ __device__ __forceinline__ void enc_slot(int f, int nfreq_per_half, int& tile, i
     tile = s >> 1, row = 16 * (s & 1) + 8 * h + j;
 }
 
-// One thread per parameter scalar.  `pi` = parameter array (get_weights order), e = flat index.
-__global__ void mlp_grad_unpack_kernel(UnpackArgs a, int pi, int in_dim, int out_dim) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+// One thread per parameter scalar of the whole network.  pi = parameter array (get_weights
+// order), e = flat index inside it.
+__global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= a.first[24]) return;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 24; ++i)
+        if (gi >= a.first[i]) pi = i;
+    const int e = gi - a.first[pi];
+    const int out_dim = kLayerDims[pi >> 1][1];
     const bool is_bias = pi & 1;
-    const int count = is_bias ? out_dim : in_dim * out_dim;
-    if (e >= count) return;
     const int layer = pi >> 1;  // 0..7 point layers, 8 bottleneck, 9 view, 10 rgb, 11 alpha
     const int in = is_bias ? -1 : e / out_dim, out = is_bias ? e : e % out_dim;
     // jobs: 0..7 = point layers (layer 5: its encoding rows + bias), 8 bottleneck, 9 alpha,
@@ -636,10 +647,11 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
         NERF_REQUIRE(grads[i], "nerf_mlp_backward: grads[%d] is null", i);
         ua.out.g[i] = grads[i];
     }
+    ua.first[0] = 0;
     for (int i = 0; i < 24; ++i) {
         const int in_dim = dims[i >> 1][0], out_dim = dims[i >> 1][1];
-        const int count = (i & 1) ? out_dim : in_dim * out_dim;
-        mlp_grad_unpack_kernel<<<(count + 255) / 256, 256, 0, st>>>(ua, i, in_dim, out_dim);
+        ua.first[i + 1] = ua.first[i] + ((i & 1) ? out_dim : in_dim * out_dim);
     }
+    mlp_grad_unpack_kernel<<<(ua.first[24] + 255) / 256, 256, 0, st>>>(ua);
     return check_launch("nerf_mlp_backward(unpack)");
 }
