@@ -61,6 +61,19 @@ int nerf_build_ray_batch(int64_t n, const float* rays_o, const float* rays_d,
                          const float* near_arr, const float* far_arr, double near, double far,
                          float* out, int width, nerf_stream_t stream);
 
+/* Training ray batches (run_nerf.py:615-656 builds a [N*H*W, ro+rd+rgb, 3] table with get_rays_np
+ * for every training pose and slices N_rand shuffled rows per step, :711-731; the no_batching
+ * branch, :736-766, gathers N_rand pixels of one image).  Both are "pixel ids -> (ray origin, ray
+ * direction, observed colour)": the rays are formed here from the pose of the pixel's image with
+ * get_rays' arithmetic, so no ray table is ever materialised.
+ * poses: [n_img,3,4] camera-to-world; images: [n_img,H,W,channels] fp32 (first 3 channels are
+ * used; NULL: no colours wanted); img_index, pix_index: [n] int32, pixel = row*W + column.
+ * out_rays: [2,n,3] (origins then directions, the layout render(rays=...) takes); out_rgb: [n,3]. */
+int nerf_gather_pixel_rays(int H, int W, double focal, int n_img, const float* poses,
+                           const float* images, int channels, const int32_t* img_index,
+                           const int32_t* pix_index, int64_t n, float* out_rays, float* out_rgb,
+                           nerf_stream_t stream);
+
 /* ---- positional encoding (standalone form) ------------------------------------------------ */
 
 /* Embedder.embed (run_nerf_helpers.py:22-56): out[m, 3+6L] = [x, sin(x 2^0), cos(x 2^0), ...]. */

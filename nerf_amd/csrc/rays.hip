@@ -40,6 +40,38 @@ __global__ void get_rays_kernel(int H, int W, float half_w, float half_h, float 
     }
 }
 
+// Rays and colours of n pixels picked from a set of posed images: get_rays' arithmetic per pixel
+// with that image's pose (bit-identical to a lookup in the table run_nerf.py:634-656 builds).
+__global__ void gather_pixel_rays_kernel(int H, int W, float half_w, float half_h, float focal,
+                                         int n_img, const float* __restrict__ poses,
+                                         const float* __restrict__ images, int channels,
+                                         const int32_t* __restrict__ img_index,
+                                         const int32_t* __restrict__ pix_index, int64_t n,
+                                         float* __restrict__ out_rays, float* __restrict__ out_rgb) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int im = img_index[idx], pix = pix_index[idx];
+    im = im < 0 ? 0 : (im >= n_img ? n_img - 1 : im);  // the host validates; never read out of bounds
+    pix = pix < 0 ? 0 : (pix >= H * W ? H * W - 1 : pix);
+    const int j = pix / W, i = pix - j * W;
+    const float* c2w = poses + (size_t)im * 12;
+    float d0 = ((float)i - half_w) / focal;
+    float d1 = -((float)j - half_h) / focal;
+    float d2 = -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = d0 * c2w[4 * k + 0] + d1 * c2w[4 * k + 1];
+        s = s + d2 * c2w[4 * k + 2];
+        out_rays[(n + idx) * 3 + k] = s;
+        out_rays[idx * 3 + k] = c2w[4 * k + 3];
+    }
+    if (images) {
+        const float* px = images + ((size_t)im * H * W + pix) * channels;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out_rgb[idx * 3 + k] = px[k];
+    }
+}
+
 // ndc_rays (run_nerf_helpers.py:163-175).  cw = -1/(W/(2f)), ch = -1/(H/(2f)) are formed on
 // the host in double, as the reference's Python scalars are, then rounded to fp32.
 __device__ __forceinline__ void ndc_project(float near, float cw, float ch, float (&o)[3],
@@ -158,6 +190,22 @@ NERF_API int nerf_get_rays(int H, int W, double focal, const float* c2w, float* 
     get_rays_kernel<<<blocks_for(n, 256), 256, 0, as_stream(stream)>>>(
         H, W, (float)(W * .5), (float)(H * .5), (float)focal, m, rays_o, rays_d);
     return check_launch("nerf_get_rays");
+}
+
+NERF_API int nerf_gather_pixel_rays(int H, int W, double focal, int n_img, const float* poses,
+                                    const float* images, int channels, const int32_t* img_index,
+                                    const int32_t* pix_index, int64_t n, float* out_rays,
+                                    float* out_rgb, nerf_stream_t stream) {
+    NERF_REQUIRE(H > 0 && W > 0 && n_img > 0 && n >= 0, "nerf_gather_pixel_rays: bad size");
+    NERF_REQUIRE((int64_t)H * W <= 0x7fffffffLL, "nerf_gather_pixel_rays: image too large for int32 pixel ids");
+    NERF_REQUIRE(poses && img_index && pix_index && out_rays, "nerf_gather_pixel_rays: null pointer");
+    NERF_REQUIRE((images == nullptr) == (out_rgb == nullptr), "nerf_gather_pixel_rays: images and out_rgb go together");
+    NERF_REQUIRE(images == nullptr || channels >= 3, "nerf_gather_pixel_rays: images need >= 3 channels, got %d", channels);
+    if (n == 0) return 0;
+    gather_pixel_rays_kernel<<<blocks_for(n, 256), 256, 0, as_stream(stream)>>>(
+        H, W, (float)(W * .5), (float)(H * .5), (float)focal, n_img, poses, images, channels, img_index,
+        pix_index, n, out_rays, out_rgb);
+    return check_launch("nerf_gather_pixel_rays");
 }
 
 NERF_API int nerf_ndc_rays(int64_t n, int H, int W, double focal, double near,

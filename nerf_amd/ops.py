@@ -76,6 +76,36 @@ def build_ray_batch(rays_o, rays_d, view_src, ndc, H, W, focal, near, far):
     return out
 
 
+def gather_pixel_rays(H, W, focal, poses, images, img_index, pix_index):
+    """(batch_rays [2,n,3], target [n,3] or None) for pixels pix_index (row*W+col) of images img_index.
+    poses [n_img,3,4] fp32 and images [n_img,H,W,C>=3] fp32 (or None) live on the GPU."""
+    poses = nv.f32(poses)
+    dev = poses.device
+    if poses.dim() != 3 or tuple(poses.shape[1:]) != (3, 4):
+        raise ValueError(f"gather_pixel_rays: poses must be [n_img,3,4], got {tuple(poses.shape)}")
+    n_img = poses.shape[0]
+    channels = 0
+    if images is not None:
+        images = nv.f32(images, dev)
+        if images.dim() != 4 or tuple(images.shape[:3]) != (n_img, H, W) or images.shape[3] < 3:
+            raise ValueError(f"gather_pixel_rays: images must be [{n_img},{H},{W},>=3], got {tuple(images.shape)}")
+        channels = images.shape[3]
+    ii = torch.as_tensor(img_index, device=dev).to(torch.int32).contiguous().reshape(-1)
+    pi = torch.as_tensor(pix_index, device=dev).to(torch.int32).contiguous().reshape(-1)
+    if ii.shape != pi.shape:
+        raise ValueError("gather_pixel_rays: img_index and pix_index differ in length")
+    n = ii.numel()
+    rays = torch.empty((2, n, 3), dtype=torch.float32, device=dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev) if images is not None else None
+    if n == 0:
+        return rays, rgb
+    with torch.cuda.device(dev):
+        nv.check(nv.lib().nerf_gather_pixel_rays(int(H), int(W), float(focal), n_img, nv.ptr(poses), nv.ptr(images),
+                                                 channels, nv.ptr(ii), nv.ptr(pi), n, nv.ptr(rays), nv.ptr(rgb),
+                                                 nv.stream()), "nerf_gather_pixel_rays")
+    return rays, rgb
+
+
 def embed(x, L):
     """Embedder.embed (run_nerf_helpers.py:22-56) on [...,3] -> [..., 3+6L]."""
     x = nv.f32(x)
