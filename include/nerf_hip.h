@@ -61,6 +61,11 @@ int nerf_build_ray_batch(int64_t n, const float* rays_o, const float* rays_d,
                          const float* near_arr, const float* far_arr, double near, double far,
                          float* out, int width, nerf_stream_t stream);
 
+/* Host helper of the image reader that stands in for imageio.imread (load_blender.py:112,
+ * load_llff.py:134-140): reverses the PNG scanline filters.  raw: h rows of 1 filter byte +
+ * stride bytes (host memory); out: h x stride bytes (host memory); bpp: bytes per pixel. */
+int nerf_png_unfilter(const unsigned char* raw, int64_t h, int64_t stride, int bpp, unsigned char* out);
+
 /* Training ray batches (run_nerf.py:615-656 builds a [N*H*W, ro+rd+rgb, 3] table with get_rays_np
  * for every training pose and slices N_rand shuffled rows per step, :711-731; the no_batching
  * branch, :736-766, gathers N_rand pixels of one image).  Both are "pixel ids -> (ray origin, ray

@@ -22,6 +22,7 @@ SIGNATURES = {
     "nerf_get_rays": (_I, [_I, _I, _D, _P, _P, _P, _P]),
     "nerf_ndc_rays": (_I, [_L, _I, _I, _D, _D, _P, _P, _P, _P, _P]),
     "nerf_build_ray_batch": (_I, [_L, _P, _P, _P, _I, _I, _I, _D, _P, _P, _D, _D, _P, _I, _P]),
+    "nerf_png_unfilter": (_I, [_P, _L, _L, _I, _P]),
     "nerf_gather_pixel_rays": (_I, [_I, _I, _D, _I, _P, _P, _I, _P, _P, _L, _P, _P, _P]),
     "nerf_embed": (_I, [_L, _P, _I, _P, _P]),
     "nerf_sample_z": (_I, [_L, _I, _P, _I, _I, _P, _P, _P]),

@@ -26,29 +26,40 @@ def imwrite(path, img):
 
 
 def imread(path):
-    """Reads back PNGs written by imwrite (filter type 0 rows only)."""
+    """8-bit gray / gray+alpha / RGB / RGBA, non-interlaced PNGs with any scanline filter
+    (what the blender and LLFF data sets ship) -> uint8 [H,W] or [H,W,C]."""
     with open(path, "rb") as f:
         data = f.read()
     if data[:8] != b"\x89PNG\r\n\x1a\n":
-        raise ValueError("not a PNG")
-    pos, idat, w = 8, b"", None
+        raise ValueError(f"{path}: not a PNG")
+    pos, idat, w = 8, [], None
     while pos < len(data):
         n, tag = struct.unpack(">I4s", data[pos:pos + 8])
         body = data[pos + 8:pos + 8 + n]
         if tag == b"IHDR":
             w, h, depth, color, _, _, interlace = struct.unpack(">IIBBBBB", body)
-            if depth != 8 or interlace != 0 or color not in (0, 2, 6):
-                raise ValueError("unsupported PNG flavour")
-            c = {0: 1, 2: 3, 6: 4}[color]
+            if depth != 8 or interlace != 0 or color not in (0, 2, 4, 6):
+                raise ValueError(f"{path}: unsupported PNG flavour (depth {depth}, colour type {color}, interlace {interlace})")
+            c = {0: 1, 2: 3, 4: 2, 6: 4}[color]
         elif tag == b"IDAT":
-            idat += body
+            idat.append(body)
+        elif tag == b"IEND":
+            break
         pos += 12 + n
-    raw = zlib.decompress(idat)
-    stride = w * c + 1
-    out = np.empty((h, w, c), dtype=np.uint8)
-    for y in range(h):
-        row = raw[y * stride:(y + 1) * stride]
-        if row[0] != 0:
-            raise ValueError("PNG row filter not supported by this reader")
-        out[y] = np.frombuffer(row[1:], dtype=np.uint8).reshape(w, c)
+    if w is None:
+        raise ValueError(f"{path}: no IHDR chunk")
+    raw = zlib.decompress(b"".join(idat))
+    stride = w * c
+    if len(raw) != h * (stride + 1):
+        raise ValueError(f"{path}: truncated image data")
+    rows = np.frombuffer(raw, dtype=np.uint8).reshape(h, stride + 1)
+    if not rows[:, 0].any():                     # filter type 0 everywhere: nothing to undo
+        out = rows[:, 1:].reshape(h, w, c).copy()
+    else:
+        import ctypes
+        from . import _native as nv
+        out = np.empty((h, w, c), dtype=np.uint8)
+        src = np.ascontiguousarray(rows)
+        nv.check(nv.lib().nerf_png_unfilter(src.ctypes.data_as(ctypes.c_void_p), h, stride, c,
+                                            out.ctypes.data_as(ctypes.c_void_p)), "nerf_png_unfilter")
     return out[..., 0] if c == 1 else out
