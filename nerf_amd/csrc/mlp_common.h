@@ -82,12 +82,11 @@ DEV void wait_vmcnt_n(int n) {
     }
 }
 
-// This wave's vector-memory LOADS (ordinary and direct-to-LDS) counted at issue.  Loads retire in
-// issue order among themselves, so "every load issued up to mark m has completed" is
-// s_waitcnt vmcnt(issued - m).  Stores share the hardware counter but may retire out of order
-// with respect to loads, so they are deliberately NOT counted: an uncounted pending store can
-// only make a wait stricter, whereas a counted store that retired early would let the wait
-// pass with the wanted load still in flight.  An issue site may also undercount (stricter).
+// This wave's vector-memory operations counted at issue: loads (ordinary and direct-to-LDS) and
+// stores share one hardware counter and retire in issue order, so "everything issued up to mark m
+// has completed" is s_waitcnt vmcnt(issued - m).  An issue site may undercount (the wait then is
+// merely stricter: an uncounted older operation retires first anyway, an uncounted younger one
+// makes the wait ask for more than needed); it must never overcount.
 struct VmQueue {
     int issued = 0;
     DEV void wait_until(int mark) const { wait_vmcnt_n(issued - mark); }

@@ -48,13 +48,16 @@ constexpr int kRingBytes = FwdStream::kRingBytes;
 // Where a training forward saves its fragments: [wave tile][block][lane] (null: inference).
 struct ActSink {
     char* base;  // this lane's address inside block 0 of its wave tile
+    VmQueue* vm;
     template <int BLK>
     DEV void put(const half8& v) const {
-        *(half8*)(base + BLK * kFragBytes) = v;  // stores are not counted: see VmQueue
+        __builtin_nontemporal_store(v, (half8*)(base + BLK * kFragBytes));  // streamed: keep L2 for the weights
+        vm->issued += 1;
     }
     template <int BLK, class V>
     DEV void put_mask(const V& v) const {
-        *(V*)(base + BLK * kFragBytes) = v;
+        __builtin_nontemporal_store(v, (V*)(base + BLK * kFragBytes));
+        vm->issued += 1;
     }
 };
 
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(FwdArgs a) {
         encode<2, 16>(vd, h, 4.f, v);
         pack_slots<16>(v, vpe);
     }
-    ActSink sink{nullptr};
+    ActSink sink{nullptr, &vm};
     if constexpr (STORE) {
         const int64_t wave_tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
         sink.base = a.act + (size_t)wave_tile * kActBlocks * kFragBytes + lane * 16;

@@ -98,12 +98,11 @@ struct MaskLoad {
 
 struct GradSink {
     char* base;
+    VmQueue* vm;
     template <int BLK>
     DEV void put(const half8& v) const {
-#ifdef EXP_NO_GRAD_STORE
-        if (v[0] == (_Float16)12345.f)
-#endif
-        *(half8*)(base + BLK * kFragBytes) = v;  // stores are not counted: see VmQueue
+        __builtin_nontemporal_store(v, (half8*)(base + BLK * kFragBytes));  // streamed: keep L2 for the weights
+        vm->issued += 1;
     }
 };
 
@@ -199,7 +198,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
     MaskLoad mv, m7, m6, m5, m4, m3, m2, m1, m0;
     mv.issue(vm, masks + 8 * kFragBytes);
     m7.issue(vm, masks + 7 * kFragBytes);
-    GradSink sink{a.gbuf + (size_t)wave_tile * kGradBlocks * kFragBytes + lane * 16};
+    GradSink sink{a.gbuf + (size_t)wave_tile * kGradBlocks * kFragBytes + lane * 16, &vm};
 
     const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + (lane & 31);
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
