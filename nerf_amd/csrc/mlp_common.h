@@ -106,14 +106,21 @@ DEV void glds16(const void* gsrc, void* lds_dst) {
 // flight and would drain the whole queue (s_waitcnt vmcnt(0)) before every read.  The caller
 // owns the ordering: a counted s_waitcnt vmcnt, then a barrier if other waves read the data.
 // lds_dst must be wave-uniform.
+template <bool STREAMED = false>
 DEV void glds16_untracked(const void* gsrc, void* lds_dst) {
     const unsigned addr = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(addr)
-                 : "memory");
+    if constexpr (STREAMED)  // read-once data: do not displace what other kernels' waves keep in L2
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(addr)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(addr)
+                     : "memory");
 }
 
 // The weight stream (NCHUNKS chunks of 16 KiB, RING LDS slots, DEPTH chunks in flight) and the

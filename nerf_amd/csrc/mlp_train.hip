@@ -285,7 +285,7 @@ constexpr int kTileImgBytes = 2 * kFragBytes;
 DEV void stage_tile(const char* blocks /*lane-independent address of the pair's first block*/,
                     char* img, int n, int lane, bool one_block) {
     const int c = 16 * n + (lane >> 2), sb = one_block ? 0 : (lane >> 1) & 1, hh = lane & 1;
-    glds16_untracked(blocks + sb * kFragBytes + (32 * hh + c) * 16, img + n * kFragBytes);
+    glds16_untracked<true>(blocks + sb * kFragBytes + (32 * hh + c) * 16, img + n * kFragBytes);
 }
 
 // Operand fragment (A or B alike) of a staged tile image x the 16 points 16*kp .. 16*kp+15:
