@@ -1,8 +1,8 @@
 // Re-lays the 24 fp32 parameter arrays of one NeRF network (get_weights() order) into the fp16
 // MFMA fragment streams + fp32 bias tiles the forward kernels read: the inference stream of
 // mlp_layout_wide.h first, then the training-forward stream of mlp_layout.h.  One 64-thread block
-// per fragment / bias tile; runs once per weight update (2 x 1.2 MB out), so it is written for
-// clarity.
+// per fragment / bias tile, both streams in one launch; runs once per weight update (2 x 1.2 MB
+// out), so it is written for clarity.
 #include "common.h"
 #include "mlp_layout.h"
 #include "mlp_layout_wide.h"
@@ -17,9 +17,8 @@ struct ParamPtrs {
 // get_weights() slots (kernel at 2*i, bias at 2*i+1)
 constexpr int P_BOTT = 8, P_VIEW = 9, P_RGB = 10, P_ALPHA = 11;
 
-__global__ __launch_bounds__(64) void mlp_pack_kernel(ParamPtrs pp, char* __restrict__ packed) {
+__device__ void pack_train_fragment(const ParamPtrs& pp, char* __restrict__ packed, int F) {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    const int F = blockIdx.x;
     if (F >= F_END) {
         // bias tiles
         const int T = F - F_END;
@@ -89,10 +88,9 @@ __global__ __launch_bounds__(64) void mlp_pack_kernel(ParamPtrs pp, char* __rest
 }
 
 // The inference stream: fragment F = (output tile of 16 rows, k-step of 32 inputs).
-__global__ __launch_bounds__(64) void mlp_pack_wide_kernel(ParamPtrs pp, char* __restrict__ packed) {
+__device__ void pack_wide_fragment(const ParamPtrs& pp, char* __restrict__ packed, int F) {
     using namespace lw;
     const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-    const int F = blockIdx.x;
     if (F >= lw::F_END) {
         const int T = F - lw::F_END;  // bias tile: 16 floats in row order
         if (lane >= 16) return;
@@ -159,6 +157,13 @@ __global__ __launch_bounds__(64) void mlp_pack_wide_kernel(ParamPtrs pp, char* _
     }
 }
 
+constexpr int kWideBlocks = lw::F_END + lw::T_END, kTrainBlocks = layout::F_END + layout::BT_END;
+
+__global__ __launch_bounds__(64) void mlp_pack_kernel(ParamPtrs pp, char* __restrict__ packed) {
+    if ((int)blockIdx.x < kWideBlocks) pack_wide_fragment(pp, packed, blockIdx.x);
+    else pack_train_fragment(pp, packed + lw::kPackedBytes, blockIdx.x - kWideBlocks);
+}
+
 }  // namespace nerf
 
 using namespace nerf;
@@ -173,7 +178,6 @@ NERF_API int nerf_mlp_pack(const float* const* params, void* packed, nerf_stream
         NERF_REQUIRE(params[i], "nerf_mlp_pack: params[%d] is null", i);
         pp.p[i] = params[i];
     }
-    mlp_pack_wide_kernel<<<lw::F_END + lw::T_END, 64, 0, as_stream(stream)>>>(pp, (char*)packed);
-    mlp_pack_kernel<<<layout::F_END + layout::BT_END, 64, 0, as_stream(stream)>>>(pp, (char*)packed + lw::kPackedBytes);
+    mlp_pack_kernel<<<kWideBlocks + kTrainBlocks, 64, 0, as_stream(stream)>>>(pp, (char*)packed);
     return check_launch("nerf_mlp_pack");
 }

@@ -27,7 +27,7 @@ def mse2psnr(x):
     """run_nerf_helpers.py:14"""
     if not isinstance(x, torch.Tensor):
         x = torch.as_tensor(x, dtype=torch.float32)
-    return -10. * torch.log(x) / float(np.log(10.))
+    return torch.log(x) * float(-10. / np.log(10.))
 
 
 def to8b(x):

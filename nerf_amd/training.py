@@ -60,6 +60,7 @@ class MLPQuery(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays, z, model, *params):
+        ctx.set_materialize_grads(False)
         n, S = z.shape
         act = torch.empty((ops.act_bytes(n * S),), dtype=torch.uint8, device=rays.device)
         raw = ops.mlp_forward_train(model.packed(), rays, z, act)
@@ -69,6 +70,9 @@ class MLPQuery(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_raw):
         model = ctx.model
+        if d_raw is None:  # the network output did not reach the loss
+            ctx.act = None
+            return (None, None, None) + (None,) * len(model.params)
         d_raw = d_raw.contiguous()
         n_points = d_raw.numel() // 4
         dev = d_raw.device
@@ -90,6 +94,7 @@ class Composite(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, z, rays, white_bkgd, noise, noise_std):
+        ctx.set_materialize_grads(False)  # maps that do not reach the loss cost no kernels
         width = rays.shape[1]
         rgb, disp, acc, weights, depth = ops.composite_fwd(raw, z, rays[:, 3:6], width, white_bkgd,
                                                            noise, noise_std)
@@ -101,6 +106,8 @@ class Composite(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_weights, g_depth):
         raw, z, rays, depth, acc = ctx.saved_tensors
+        if g_rgb is None and g_disp is None and g_acc is None and g_depth is None:
+            return None, None, None, None, None, None
         if g_disp is not None:
             # disp = 1/max(1e-10, q), q = depth/acc: chain into depth and acc
             q = depth / acc
@@ -118,6 +125,7 @@ class Composite(torch.autograd.Function):
 class _MSE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y):
+        ctx.set_materialize_grads(False)
         x = x.contiguous()
         y = nv.f32(y, x.device)
         if x.shape != y.shape:
@@ -134,7 +142,7 @@ class _MSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d_x,) = ctx.saved_tensors
-        return d_x * g, None
+        return (None if g is None else d_x * g), None
 
 
 def mse(x, y):
