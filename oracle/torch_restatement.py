@@ -1,4 +1,6 @@
-"""TEST INFRASTRUCTURE ONLY -- unfused torch-CPU restatement of the reference's TF1.15 op sequence.
+"""TEST INFRASTRUCTURE ONLY -- unfused torch restatement of the reference's TF1.15 op sequence
+(CPU tensors for the timed baseline; it follows the device of its inputs, so the full-size tests
+can also run it in float64 next to the kernels).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 
@@ -81,7 +83,7 @@ def sample_pdf(bins, weights, n, det=True, u=None):
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
     if det:
-        u = torch.linspace(0., 1., n, dtype=bins.dtype).expand(list(cdf.shape[:-1]) + [n])
+        u = torch.linspace(0., 1., n, dtype=bins.dtype, device=bins.device).expand(list(cdf.shape[:-1]) + [n])
     u = u.contiguous()
     inds = torch.searchsorted(cdf.contiguous(), u, right=True)
     below = torch.clamp_min(inds - 1, 0)
@@ -98,7 +100,7 @@ def render_rays(rb, ws_c, ws_f, N_samples=64, N_importance=128, white_bkgd=False
                 perturb_u=None, pdf_u=None, netchunk=1024 * 64):
     """Upstream render_rays (see nerf_oracle.render_rays for the evidence it follows)."""
     o, d, near, far, vd = rb[:, 0:3], rb[:, 3:6], rb[:, 6:7], rb[:, 7:8], rb[:, 8:11]
-    t = torch.linspace(0., 1., N_samples, dtype=rb.dtype)
+    t = torch.linspace(0., 1., N_samples, dtype=rb.dtype, device=rb.device)
     z = near * (1. - t) + far * t if not lindisp else 1. / (1. / near * (1. - t) + 1. / far * t)
     z = z.expand(rb.shape[0], N_samples)
     if perturb_u is not None:
