@@ -123,6 +123,32 @@ DEV void glds16_untracked(const void* gsrc, void* lds_dst) {
                      : "memory");
 }
 
+// The same with the source given as a wave-uniform base (SGPR pair) plus a 32-bit per-lane byte
+// offset: address arithmetic stays on the scalar unit and a lane keeps one register per distinct
+// offset pattern instead of a 64-bit pointer per load.
+template <bool STREAMED = false>
+DEV void glds16_untracked_sbase(const void* base, unsigned lane_off, void* lds_dst) {
+    const unsigned addr = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
+    // `base` must be the same in every lane; say so to the compiler (an "s" operand it believes
+    // divergent is silently passed in vector registers)
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    const void* uniform_base = (const void*)(uintptr_t)(
+        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b));  // the builtin returns a signed int
+    unsigned keep;
+    if constexpr (STREAMED)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(uniform_base), "s"(addr)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(uniform_base), "s"(addr)
+                     : "memory");
+}
+
 // The weight stream (NCHUNKS chunks of 16 KiB, RING LDS slots, DEPTH chunks in flight) and the
 // register pipeline of A fragments.  Fragments must be taken in stream order, F = 0, 1, 2, ...
 template <int NCHUNKS, int RING, int DEPTH>

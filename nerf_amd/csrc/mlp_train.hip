@@ -5,17 +5,19 @@
 //  1. mlp_bwd_chain_kernel -- d h_l = W_{l+1} . d pre_{l+1}, masked by h_l > 0, from the rgb/alpha
 //     heads down to layer 0.  Same structure as the forward kernel: transposed products with
 //     v_mfma_f32_32x32x16_f16, the gradient of a 32-point wave tile stays in registers, the
-//     (transposed-packed) weights stream L2 -> LDS once per workgroup.  ReLU masks come from the
-//     saved activations through a small per-wave LDS ring (direct-to-LDS loads, no barrier:
-//     a wave only reads what it loaded itself).  Every d pre_l is written out as fp16 fragments.
-//     Gradients are multiplied by `gscale` on entry so that they sit inside the fp16 range.
+//     (transposed-packed) weights stream L2 -> LDS once per workgroup.  ReLU masks are the bit
+//     blocks the forward saved (one 16-byte register load per layer, issued a layer ahead).
+//     Every d pre_l is written out as fp16 fragments.  Gradients are multiplied by `gscale` on
+//     entry so that they sit inside the fp16 range.
 //  2. mlp_dw_kernel -- per layer, dW^T[out][in] = sum over points of d pre[out][pt] * x[pt][in].
 //     The contraction runs over points, which the stored fragments keep on the lane, so every
 //     operand is rebuilt with the transposing LDS read (ds_read_b64_tr_b16).  One workgroup
 //     owns a (layer, point range) pair, keeps the whole dW^T of the layer in accumulators
-//     (wave w = output tile w) and adds it to a global fp32 buffer once at the end.  A constant
-//     "ones" input column yields the bias gradient from the same product.  HBM-bound:
-//     ~10.6 KB/point read for 1.19 MFLOP/point.
+//     (wave w = output tile w) and adds it to a global fp32 buffer once at the end.  Bias
+//     gradients are the sums of the gradient operand over the points.  Layers whose input is
+//     a concatenation (layer 5, view layer) and heads that share an input (bottleneck, alpha) are
+//     one job each, so every saved block is read once.  HBM-bound: ~9.9 KB/point read for
+//     1.19 MFLOP/point.
 //  3. mlp_grad_unpack_kernel -- accumulator-ordered partial sums -> the 24 arrays, times 1/gscale.
 #include "mlp_common.h"
 
@@ -250,13 +252,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kDwStageBytes = 40 * kFragBytes;  // one ring stage: a group of wave tiles of one job
 constexpr int kDwStages = 4;
-constexpr int kNumJobs = 14;  // layers 5 and 9 have two input segments: one job each
+constexpr int kDwAhead = 3;      // input operands in flight ahead of their MFMA
+constexpr int kNumJobs = 11;     // what a workgroup can be given (see make_jobs)
+constexpr int kNumProducts = 12; // (layer input, layer gradient) products the unpack kernel reads
 
+// One job = one gradient segment y (NY tiles of 32 outputs) against one or two input segments x
+// (NX0 + NX1 tiles of 32 inputs), optionally against a second, single-row gradient y1 (the alpha
+// head shares the bottleneck's input).
 struct DwJob {
-    int x0_blk, x0_k;    // input segment: block in the activation buffer, k-steps
-    int bias;            // 1: a trailing ones tile yields the bias gradient
-    int y_blk, y_k;      // gradient segment: block in the gradient buffer, k-steps (1 or even)
-    int n_in;            // input tiles including the ones tile
+    int kind;            // which dw_body instantiation (see mlp_dw_kernel)
+    int x0_blk, x1_blk;  // input segments: first block in the activation buffer
+    int y_blk, y1_blk;   // gradient segments: first block in the gradient buffer
+    int y_k;             // blocks of y (1 or even)
     int n_out;           // output tiles (<= 8): wave w owns output tile w
     int tile0;           // first 32x32 tile of this job in the partial-sum buffer
     int wg0, wgs;        // workgroups [wg0, wg0 + wgs) split the wave tiles of this job
@@ -268,7 +275,7 @@ struct DwArgs {
     float* gperm;        // [tiles][16 regs][64 lanes]
     int64_t wave_tiles;
     DwJob job[kNumJobs];
-#ifdef DW_STAMPS
+#ifdef DW_STAMPS  // diagnostic build only: per-workgroup (begin, end, job) timestamps
     unsigned long long* stamps;
 #endif
 };
@@ -282,10 +289,11 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 // address: LDS lane L of load n (n = 0, 1) fetches point 16n + L/4, block (L>>1)&1, half L&1.
 constexpr int kTileImgBytes = 2 * kFragBytes;
 
-DEV void stage_tile(const char* blocks /*lane-independent address of the pair's first block*/,
-                    char* img, int n, int lane, bool one_block) {
-    const int c = 16 * n + (lane >> 2), sb = one_block ? 0 : (lane >> 1) & 1, hh = lane & 1;
-    glds16_untracked<true>(blocks + sb * kFragBytes + (32 * hh + c) * 16, img + n * kFragBytes);
+// Per-lane byte offset of a tile-image load inside its pair of stored blocks (load n = 0, 1 of
+// the image adds 256 n bytes, which the caller folds into the wave-uniform base address).
+DEV unsigned stage_lane_offset(int lane, bool one_block) {
+    const int c = lane >> 2, sb = one_block ? 0 : (lane >> 1) & 1, hh = lane & 1;
+    return (unsigned)(sb * kFragBytes + (32 * hh + c) * 16);
 }
 
 // Operand fragment (A or B alike) of a staged tile image x the 16 points 16*kp .. 16*kp+15:
@@ -302,23 +310,86 @@ DEV half8 tr_operand(const char* img, int kp, int lane, bool one_block) {
     return __builtin_bit_cast(half8, v);
 }
 
-// One workgroup's share of a job with NX input tiles (+ the ones tile when BIAS) and NY gradient
-// tiles per wave tile.  G wave tiles form one ring stage (one barrier, one counted wait), chosen
-// so that a stage is 30-40 KiB whatever the job: a workgroup then always has ~100 KiB of loads
-// in flight, which is what keeps the narrow jobs (rgb, alpha, encoding rows) off the latency
-// bound.  The loads of a stage are dealt round-robin to the 8 waves and padded with repeats to
-// the same count kMine for every wave, so the vmcnt bookkeeping is a compile-time constant.
-//
-// ROW: the job has one output tile (alpha, rgb).  Giving it to one wave would leave that wave
-// alone with every MFMA of the job, so the waves split the INPUT tiles instead: wave w
-// accumulates the product with input tile w (wave 0 also takes the ones tile).
-template <int NX, int NY, int BIAS, int G, bool ROW = false>
-DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave) {
-    constexpr int NI = NX + BIAS;
-    static_assert(!ROW || (NY == 1 && NX <= kWavesPerBlock), "row jobs: one gradient tile, one input tile per wave");
-    constexpr int kTileUnits = 2 * (NX + NY);                  // 1 KiB loads per wave tile
-    constexpr int kUnits = kTileUnits * G;                     // per stage
+// Stages a group of G wave tiles of a job into one ring stage (a tile index past the end
+// re-loads the last tile: the loads stay in bounds and a wave issues the same number of loads
+// for every stage).  The 1 KiB loads of a stage are dealt round-robin to the 8 waves.  Which
+// block a load fetches is wave-uniform (scalar arithmetic);
+// the lanes only add one of two offsets.  Everything is passed by value: an object
+// whose address is taken would live in scratch and be re-read after every inline-asm load.
+struct DwStageSrc {
+    const char* act;
+    const char* gbuf;
+    int x0_blk, x1_blk, y_blk, y1_blk;
+    bool y_one;
+    int64_t t_lo, t_hi;
+    unsigned off_two, off_one;  // per-lane offsets: two-block / one-block tile images
+};
+
+template <int NX0, int NX1, int NY, int NY1, int G>
+DEV void dw_stage_in(const DwStageSrc s, int64_t group, char* dst, int wave) {
+    constexpr int NX = NX0 + NX1;
+    constexpr int kTileUnits = 2 * (NX + NY + NY1), kUnits = kTileUnits * G;
     constexpr int kMine = (kUnits + kWavesPerBlock - 1) / kWavesPerBlock;
+    // base addresses of the G wave tiles once per stage (64-bit scalar multiplies), then a few
+    // 32-bit scalar operations per load
+    const char* abase[G];
+    const char* gbase[G];
+#pragma unroll
+    for (int gt = 0; gt < G; ++gt) {
+        int64_t wt = s.t_lo + group * G + gt;
+        if (wt >= s.t_hi) wt = s.t_hi - 1;
+        abase[gt] = s.act + (size_t)wt * kActBlocks * kFragBytes;
+        gbase[gt] = s.gbuf + (size_t)wt * kGradBlocks * kFragBytes;
+    }
+#pragma unroll
+    for (int m = 0; m < kMine; ++m) {
+        const int u = wave + m * kWavesPerBlock;
+        if (u >= kUnits) break;  // only in the last round, only for waves >= kUnits % 8
+        int gt = 0, r = u;
+        if constexpr (G > 1) gt = u / kTileUnits, r = u % kTileUnits;
+        const int img = r >> 1, n = r & 1;
+        const bool is_x = img < NX;
+        const int blk = img < NX0 ? s.x0_blk + 2 * img
+                      : img < NX ? s.x1_blk + 2 * (img - NX0)
+                      : img < NX + NY ? s.y_blk + 2 * (img - NX)
+                                      : s.y1_blk;
+        const bool one = !is_x && (img >= NX + NY || s.y_one);
+        const char* ab = abase[0];
+        const char* gb = gbase[0];
+#pragma unroll
+        for (int k = 1; k < G; ++k)
+            if (gt == k) ab = abase[k], gb = gbase[k];
+        const char* src = (is_x ? ab : gb) + (unsigned)(blk * kFragBytes + n * 256);
+        glds16_untracked_sbase<true>(src, one ? s.off_one : s.off_two, dst + (unsigned)(u * kFragBytes));
+    }
+}
+
+// One workgroup's share of a job: NX = NX0 + NX1 input tiles (+ the bias column when BIAS), NY
+// gradient tiles and, when NY1, one more single-row gradient tile per wave tile.  G wave tiles form
+// one ring stage (one barrier, one counted wait), chosen so that a stage is 26-40 KiB whatever the
+// job: a workgroup then always has ~100 KiB of loads in flight, which is what keeps the narrow
+// jobs (rgb, encoding rows) off the latency bound.  The loads of a stage are dealt round-robin to
+// the 8 waves (kMine each, one fewer for the waves past the remainder), so the vmcnt bookkeeping
+// is a compile-time constant per wave class.  The kernel's time is set by the number of 1 KiB
+// loads a workgroup issues (measured: 48 ns each per CU, whatever the job), so no load is
+// issued twice and workgroups are handed out in proportion to the loads of a job.
+//
+// Accumulator tiles of the partial-sum buffer, from jb.tile0: output tile w x input i at
+// w * NI + i (i = NX: the bias, in column 0); the single-row gradient x input i at n_out * NI + i.
+//
+// ROW: the job has one output tile (rgb).  Giving it to one wave would leave that wave alone with
+// every MFMA of the job, so the waves split the INPUT tiles instead: wave w accumulates the
+// product with input tile w (wave 0 also takes the bias).  The single-row gradient of an NY1
+// job is handled the same way on top of the wave's own output tile.
+template <int NX0, int NX1, int NY, int NY1, int BIAS, int G, bool ROW = false>
+DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave) {
+    constexpr int NX = NX0 + NX1, NI = NX + BIAS;
+    static_assert(!ROW || (NY == 1 && NY1 == 0 && NX <= kWavesPerBlock), "row jobs: one gradient tile, one input tile per wave");
+    static_assert(NY1 == 0 || (NY1 == 1 && !ROW && NX <= kWavesPerBlock), "a second gradient is a single row split over the waves");
+    constexpr int kTileUnits = 2 * (NX + NY + NY1);            // 1 KiB loads per wave tile
+    constexpr int kUnits = kTileUnits * G;                     // per stage
+    constexpr int kMine = (kUnits + kWavesPerBlock - 1) / kWavesPerBlock;  // loads per stage of waves < kFullWaves,
+    constexpr int kFullWaves = kUnits - (kMine - 1) * kWavesPerBlock;       // the other waves issue one fewer
     constexpr int kTileBytes = kTileUnits * kFragBytes;
     static_assert(kTileBytes * G <= kDwStageBytes, "stage size");
     const int slice = blockIdx.x - jb.wg0;
@@ -328,35 +399,28 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
     const int64_t ntile = t_hi - t_lo;
     const int64_t nstage = (ntile + G - 1) / G;
 
-    // stage a group of wave tiles (a tile index past the end re-loads the last tile: the loads
-    // stay in bounds and the count per wave stays kMine)
-    auto stage_in = [&](int64_t group, int sbuf) {
-        char* dst = lds + sbuf * kDwStageBytes;
-#pragma unroll
-        for (int m = 0; m < kMine; ++m) {
-            int u = wave + m * kWavesPerBlock;
-            if (u >= kUnits) u -= kUnits;
-            const int gt = u / kTileUnits, r = u % kTileUnits, img = r >> 1;
-            int64_t wt = t_lo + group * G + gt;
-            if (wt >= t_hi) wt = t_hi - 1;
-            char* timg = dst + gt * kTileBytes + img * kTileImgBytes;
-            if (img < NX)
-                stage_tile(a.act + ((size_t)wt * kActBlocks + jb.x0_blk) * kFragBytes + (size_t)img * kTileImgBytes,
-                           timg, r & 1, lane, false);
-            else
-                stage_tile(a.gbuf + ((size_t)wt * kGradBlocks + jb.y_blk) * kFragBytes + (size_t)(img - NX) * kTileImgBytes,
-                           timg, r & 1, lane, y_one);
-        }
+    const DwStageSrc src{a.act, a.gbuf, jb.x0_blk, jb.x1_blk, jb.y_blk, jb.y1_blk, y_one, t_lo, t_hi,
+                         stage_lane_offset(lane, false), stage_lane_offset(lane, true)};
+    auto stage_in = [=](int64_t group, int sbuf) {
+        dw_stage_in<NX0, NX1, NY, NY1, G>(src, group, lds + sbuf * kDwStageBytes, wave);
     };
 
-    constexpr int NACC = ROW ? 2 : NI;
+    constexpr int NACC = ROW ? 1 : NX;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i)
-        acc[i] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // constant operand of the ones column: input slot 0 is 1 for every point
-    half8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
-    if ((lane & 31) == 0) ones = half8{1, 1, 1, 1, 1, 1, 1, 1};
+    for (int i = 0; i < NACC; ++i) acc[i] = zero16;
+    f32x16 accr = zero16;  // NY1: single-row gradient x input tile `wave`
+    // Bias gradients = sums of the gradient operand over the points.  A lane of that operand holds
+    // 8 points of output row (lane & 31), so one fp32 register per lane takes the sum (v_dot2 with
+    // ones) and the two lane halves meet in the atomic add at the end.
+    float bsum = 0.f, bsum_r = 0.f;
+    auto point_sum = [](const half8& v, float s) {
+        const half2v one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) s = __builtin_amdgcn_fdot2(half2v{v[j], v[j + 1]}, one, s, false);
+        return s;
+    };
 
     constexpr int kAhead = kDwStages - 1;  // stages in flight beyond the one being consumed
 #pragma unroll
@@ -370,15 +434,23 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
             constexpr int buf = decltype(sc)::value;
             const int64_t it = it0 + buf;
             if (it < nstage) {
-                // everything but the loads of the stages after this one has landed
+                // everything but this wave's loads of the stages after this one has landed
                 const int64_t left = nstage - 1 - it;
-                if (left >= kAhead - 1) wait_vmcnt_n((kAhead - 1) * kMine);
-                else if (left == 1) wait_vmcnt_n(kMine);
-                else wait_vmcnt_n(0);
+                if (wave < kFullWaves) {
+                    if (left >= kAhead - 1) wait_vmcnt_n((kAhead - 1) * kMine);
+                    else if (left == 1) wait_vmcnt_n(kMine);
+                    else wait_vmcnt_n(0);
+                } else {
+                    if (left >= kAhead - 1) wait_vmcnt_n((kAhead - 1) * (kMine - 1));
+                    else if (left == 1) wait_vmcnt_n(kMine - 1);
+                    else wait_vmcnt_n(0);
+                }
                 asm volatile("s_barrier" ::: "memory");
                 // the buffer read in the previous iteration is free again (every wave passed the barrier)
                 constexpr int nbuf = (buf + kAhead) % kDwStages;
+#ifndef EXP_DW_NOLOAD
                 if (it + kAhead < nstage) stage_in(it + kAhead, nbuf);
+#endif
                 if constexpr (ROW) {
                     if (wave < NX) {
 #pragma unroll
@@ -389,23 +461,51 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
                                 for (int kp = 0; kp < 2; ++kp) {
                                     const half8 ya = tr_operand(stage + NX * kTileImgBytes, kp, lane, y_one);
                                     acc[0] = mfma(ya, tr_operand(stage + wave * kTileImgBytes, kp, lane, false), acc[0]);
-                                    if (BIAS && wave == 0) acc[1] = mfma(ya, ones, acc[1]);
+                                    if constexpr (BIAS) bsum = point_sum(ya, bsum);
                                 }
                             }
                         }
                     }
-                } else if (wave < jb.n_out) {
+                } else {
+                    if (wave < jb.n_out) {
 #pragma unroll
-                    for (int gt = 0; gt < G; ++gt) {
-                        if (it * G + gt < ntile) {
-                            const char* stage = lds + buf * kDwStageBytes + gt * kTileBytes;
+                        for (int gt = 0; gt < G; ++gt) {
+                            if (it * G + gt < ntile) {
+                                const char* stage = lds + buf * kDwStageBytes + gt * kTileBytes;
+                                // 2 NX products, input operands read kDwAhead products ahead of
+                                // their MFMA (the compiler, left alone, reads each operand right
+                                // before its use and every MFMA then waits a full LDS round trip)
+                                half8 ya[2], q[kDwAhead];
+                                ya[0] = tr_operand(stage + (NX + wave) * kTileImgBytes, 0, lane, y_one);
+                                ya[1] = tr_operand(stage + (NX + wave) * kTileImgBytes, 1, lane, y_one);
+                                half8 yr[2], xr[2];  // NY1: the single-row gradient and this wave's input tile
+                                if constexpr (NY1) {
 #pragma unroll
-                            for (int kp = 0; kp < 2; ++kp) {
-                                const half8 ya = tr_operand(stage + (NX + wave) * kTileImgBytes, kp, lane, y_one);
-#pragma unroll
-                                for (int i = 0; i < NX; ++i)
-                                    acc[i] = mfma(ya, tr_operand(stage + i * kTileImgBytes, kp, lane, false), acc[i]);
-                                if constexpr (BIAS) acc[NX] = mfma(ya, ones, acc[NX]);
+                                    for (int kp = 0; kp < 2; ++kp) {
+                                        yr[kp] = tr_operand(stage + (NX + NY) * kTileImgBytes, kp, lane, true);
+                                        xr[kp] = tr_operand(stage + wave * kTileImgBytes, kp, lane, false);
+                                    }
+                                }
+                                static_for<0, kDwAhead>([&](auto mc) {
+                                    constexpr int m = decltype(mc)::value;
+                                    q[m] = tr_operand(stage + (m % NX) * kTileImgBytes, m / NX, lane, false);
+                                });
+                                __builtin_amdgcn_sched_barrier(0);
+                                static_for<0, 2 * NX>([&](auto mc) {
+                                    constexpr int m = decltype(mc)::value, i = m % NX, kp = m / NX;
+                                    const half8 b = q[m % kDwAhead];
+                                    if constexpr (m + kDwAhead < 2 * NX) {
+                                        constexpr int m2 = m + kDwAhead;
+                                        q[m % kDwAhead] = tr_operand(stage + (m2 % NX) * kTileImgBytes, m2 / NX, lane, false);
+                                    }
+                                    acc[i] = mfma(ya[kp], b, acc[i]);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                });
+                                if constexpr (BIAS) bsum = point_sum(ya[1], point_sum(ya[0], bsum));
+                                if constexpr (NY1) {
+                                    accr = mfma(yr[1], xr[1], mfma(yr[0], xr[0], accr));
+                                    if constexpr (BIAS) bsum_r = point_sum(yr[1], point_sum(yr[0], bsum_r));
+                                }
                             }
                         }
                     }
@@ -414,49 +514,64 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
         });
     }
     // add this workgroup's partial dW^T to the global buffer (256 contiguous bytes per register)
+    auto flush = [&](int tile, const f32x16& v) {
+        float* dst = a.gperm + ((size_t)tile * 16) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, v[r]);
+    };
+    // a bias gradient goes where the product with a ones column would have put it: column 0 of
+    // the tile, output row r = lane & 31 -> register (r & 3) + 4 (r >> 3) of lane 32 ((r >> 2) & 1)
+    auto flush_bias = [&](int tile, float v) {
+        const int r = lane & 31;
+        atomicAdd(a.gperm + ((size_t)tile * 16 + (r & 3) + 4 * (r >> 3)) * 64 + 32 * ((r >> 2) & 1), v);
+    };
+    if (ntile <= 0) return;
     if constexpr (ROW) {
-        if (wave < NX && ntile > 0) {
-            float* dst = a.gperm + ((size_t)(jb.tile0 + wave) * 16) * 64 + lane;
+        if (wave < NX) flush(jb.tile0 + wave, acc[0]);
+        if (BIAS && wave == 0) flush_bias(jb.tile0 + NX, bsum);
+    } else {
+        if (wave < jb.n_out) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, acc[0][r]);
-            if (BIAS && wave == 0) {
-                dst = a.gperm + ((size_t)(jb.tile0 + NX) * 16) * 64 + lane;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, acc[1][r]);
-            }
+            for (int i = 0; i < NX; ++i) flush(jb.tile0 + wave * NI + i, acc[i]);
+            if constexpr (BIAS) flush_bias(jb.tile0 + wave * NI + NX, bsum);
         }
-    } else if (wave < jb.n_out && ntile > 0) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float* dst = a.gperm + ((size_t)(jb.tile0 + wave * NI + i) * 16) * 64 + lane;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, acc[i][r]);
+        if constexpr (NY1) {
+            if (wave < NX) flush(jb.tile0 + jb.n_out * NI + wave, accr);
+            if (BIAS && wave == 0) flush_bias(jb.tile0 + jb.n_out * NI + NX, bsum_r);
         }
     }
 }
+
+enum DwKind { DW_HIDDEN, DW_LAYER0, DW_LAYER5, DW_BOTT_ALPHA, DW_VIEW, DW_RGB };
 
 __global__ __launch_bounds__(512) void mlp_dw_kernel(DwArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[kDwStages * kDwStageBytes];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int ji = 0;  // which job this workgroup belongs to
+    // which job this workgroup belongs to: a select chain over constant indices keeps the job
+    // in scalar registers (indexing the argument array at run time would move it to scratch)
+    int ji = 0;
+    DwJob jb = a.job[0];
 #pragma unroll
     for (int j = 1; j < kNumJobs; ++j)
-        if ((int)blockIdx.x >= a.job[j].wg0) ji = j;
-    const DwJob jb = a.job[ji];
-    const int nx = jb.x0_k / 2, ny = (jb.y_k + 1) / 2;
+        if ((int)blockIdx.x >= a.job[j].wg0) jb = a.job[j], ji = j;
+    (void)ji;
 #ifdef DW_STAMPS
-    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-    struct Stamp { unsigned long long* p; unsigned long long t0; int j;
-        __device__ ~Stamp() { if (threadIdx.x == 0) { p[3 * blockIdx.x] = t0; p[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); p[3 * blockIdx.x + 2] = j; } } } stamp{a.stamps, t_begin, ji};
+    struct Stamp {
+        unsigned long long* p; unsigned long long t0; int j;
+        __device__ ~Stamp() {
+            if (threadIdx.x == 0) p[3 * blockIdx.x] = t0, p[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(), p[3 * blockIdx.x + 2] = j;
+        }
+    } stamp{a.stamps, __builtin_amdgcn_s_memrealtime(), ji};
 #endif
-    if (nx == 8 && ny == 8 && jb.bias) dw_body<8, 8, 1, 1>(a, jb, lds, lane, wave);       // hidden layers, bottleneck
-    else if (nx == 8 && ny == 8) dw_body<8, 8, 0, 1>(a, jb, lds, lane, wave);            // layer 5, h4 rows
-    else if (nx == 2) dw_body<2, 8, 1, 2>(a, jb, lds, lane, wave);                       // encoding rows of layers 0, 5
-    else if (nx == 8 && ny == 1) dw_body<8, 1, 1, 2, true>(a, jb, lds, lane, wave);      // alpha
-    else if (nx == 8) dw_body<8, 4, 1, 1>(a, jb, lds, lane, wave);                       // view layer, bottleneck rows
-    else if (nx == 4) dw_body<4, 1, 1, 3, true>(a, jb, lds, lane, wave);                 // rgb
-    else dw_body<1, 4, 0, 3>(a, jb, lds, lane, wave);                                    // view layer, view-encoding rows
+    switch (jb.kind) {
+        case DW_HIDDEN: dw_body<8, 0, 8, 0, 1, 1>(a, jb, lds, lane, wave); break;        // layers 1-4, 6, 7
+        case DW_LAYER0: dw_body<2, 0, 8, 0, 1, 2>(a, jb, lds, lane, wave); break;        // point encoding -> 256
+        case DW_LAYER5: dw_body<8, 2, 8, 0, 1, 1>(a, jb, lds, lane, wave); break;        // [h4 ; point encoding] -> 256
+        case DW_BOTT_ALPHA: dw_body<8, 0, 8, 1, 1, 1>(a, jb, lds, lane, wave); break;    // h7 -> bottleneck and alpha
+        case DW_VIEW: dw_body<8, 1, 4, 0, 1, 1>(a, jb, lds, lane, wave); break;          // [bottleneck ; view encoding] -> 128
+        default: dw_body<4, 0, 1, 0, 1, 3, true>(a, jb, lds, lane, wave); break;         // rgb
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,8 +586,8 @@ struct UnpackArgs {
     GradPtrs out;
     float inv_scale;
     int accumulate;
-    int tile0[kNumJobs];
-    int n_in[kNumJobs];
+    int tile0[kNumProducts];  // per product (0..7 point layers, 8 bottleneck, 9 view, 10 rgb, 11 alpha):
+    int n_in[kNumProducts];   // first accumulator tile, and input tiles per output tile (bias tile last)
     int first[25];  // first flat index of each parameter array (get_weights order); [24] = total
 };
 
@@ -516,18 +631,17 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
     const bool is_bias = pi & 1;
     const int layer = pi >> 1;  // 0..7 point layers, 8 bottleneck, 9 view, 10 rgb, 11 alpha
     const int in = is_bias ? -1 : e / out_dim, out = is_bias ? e : e % out_dim;
-    // jobs: 0..7 = point layers (layer 5: its encoding rows + bias), 8 bottleneck, 9 alpha,
-    // 10 view layer (bottleneck rows + bias), 11 rgb, 12 = layer 5's h4 rows, 13 = view layer's
-    // view-encoding rows
-    int job = layer <= 8 ? layer : (layer == 9 ? 10 : (layer == 10 ? 11 : 9));
     int ot, orow, it, irow;
     if (layer == 10 || layer == 11) ot = 0, orow = out;           // d rgb slots 0..2 / d alpha slot 0
     else acc_slot(out, ot, orow);
-    if (is_bias) it = a.n_in[job] - 1, irow = 0;
+    if (is_bias) it = a.n_in[layer] - 1, irow = 0;
     else if (layer == 0) enc_slot(in, 5, it, irow);
-    else if (layer == 5) { if (in < 63) enc_slot(in, 5, it, irow); else { acc_slot(in - 63, it, irow); job = 12; } }
-    else if (layer == 9) { if (in < 256) acc_slot(in, it, irow); else { enc_slot(in - 256, 2, it, irow); job = 13; } }
-    else acc_slot(in, it, irow);
+    else if (layer == 5) {       // input tiles: h4 (8), then the point encoding (2)
+        if (in < 63) { enc_slot(in, 5, it, irow); it += 8; } else acc_slot(in - 63, it, irow);
+    } else if (layer == 9) {     // input tiles: bottleneck (8), then the view encoding (1)
+        if (in < 256) acc_slot(in, it, irow); else { enc_slot(in - 256, 2, it, irow); it += 8; }
+    } else acc_slot(in, it, irow);
+    const int job = layer;
     const int n_in = a.n_in[job];
     const int reg = (orow & 3) + 4 * (orow >> 3), lane = 32 * ((orow >> 2) & 1) + irow;
     const float v = a.gperm[((size_t)(a.tile0[job] + ot * n_in + it) * 16 + reg) * 64 + lane] * a.inv_scale;
@@ -535,35 +649,58 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
     *dst = a.accumulate ? *dst + v : v;
 }
 
-// the (layer input segment, layer gradient) products
-static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs) {
-    auto set = [&](int j, int xb, int xk, int bias, int yb, int yk, int n_out) {
-        jb[j].x0_blk = xb, jb[j].x0_k = xk, jb[j].bias = bias;
-        jb[j].y_blk = yb, jb[j].y_k = yk, jb[j].n_in = xk / 2 + bias, jb[j].n_out = n_out;
+// The jobs of one network, their accumulator tiles in the partial-sum buffer and their share of
+// `total_wgs` workgroups (in proportion to the 1 KiB loads a job issues per wave tile).  prod_tile0 / prod_n_in tell
+// the unpack kernel where each layer's product lives.
+static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs, int* prod_tile0 = nullptr, int* prod_n_in = nullptr) {
+    int blocks[kNumJobs], n_acc[kNumJobs], layer_of[kNumJobs];
+    int nj = 0;
+    auto add = [&](int layer, int kind, int x0, int x1, int yb, int y1b, int yk, int n_out, int n_in, int row_tiles, int nloads) {
+        jb[nj] = DwJob{kind, x0, x1, yb, y1b, yk, n_out, 0, 0, 0};
+        blocks[nj] = nloads, n_acc[nj] = n_in * n_out + row_tiles, layer_of[nj] = layer;
+        if (prod_n_in) prod_n_in[layer] = n_in;
+        ++nj;
     };
-    set(0, A_PE, 4, 1, G_DPRE0, 16, 8);
-    for (int l = 1; l <= 7; ++l)
-        if (l != 5) set(l, A_H0 + 16 * (l - 1), 16, 1, G_DPRE0 + 16 * l, 16, 8);
-    set(5, A_PE, 4, 1, G_DPRE0 + 16 * 5, 16, 8);             // layer 5, encoding rows + bias
-    set(12, A_H0 + 16 * 4, 16, 0, G_DPRE0 + 16 * 5, 16, 8);  // layer 5, h4 rows
-    set(8, A_H0 + 16 * 7, 16, 1, G_DBOTT, 16, 8);            // bottleneck
-    set(9, A_H0 + 16 * 7, 16, 1, G_DA, 1, 1);                // alpha
-    set(10, A_BOTT, 16, 1, G_DV, 8, 4);                      // view layer, bottleneck rows + bias
-    set(13, A_VPE, 2, 0, G_DV, 8, 4);                        // view layer, view-encoding rows
-    set(11, A_V, 8, 1, G_DC, 1, 1);                          // rgb
+    add(0, DW_LAYER0, A_PE, 0, G_DPRE0, 0, 16, 8, 3, 0, 4 + 16);
+    for (int l = 1; l <= 7; ++l) {
+        if (l == 5) add(5, DW_LAYER5, A_H0 + 16 * 4, A_PE, G_DPRE0 + 16 * 5, 0, 16, 8, 11, 0, 16 + 4 + 16);
+        else add(l, DW_HIDDEN, A_H0 + 16 * (l - 1), 0, G_DPRE0 + 16 * l, 0, 16, 8, 9, 0, 32);
+    }
+    add(8, DW_BOTT_ALPHA, A_H0 + 16 * 7, 0, G_DBOTT, G_DA, 16, 8, 9, 9, 16 + 16 + 2 + 2);   // + alpha: 8 input tiles + bias (+2: the extra product)
+    add(9, DW_VIEW, A_BOTT, A_VPE, G_DV, 0, 8, 4, 10, 0, 16 + 2 + 8);
+    add(10, DW_RGB, A_V, 0, G_DC, 0, 1, 1, 5, 0, 8 + 2 + 2);                             // (+2: short stages, unpipelined)
     int tiles = 0, bytes = 0;
-    for (int j = 0; j < kNumJobs; ++j) {
+    for (int j = 0; j < nj; ++j) {
         jb[j].tile0 = tiles;
-        tiles += jb[j].n_in * jb[j].n_out;
-        bytes += jb[j].x0_k + jb[j].y_k;
+        if (prod_tile0) prod_tile0[layer_of[j]] = tiles;
+        tiles += n_acc[j];
+        bytes += blocks[j];
+    }
+    if (prod_tile0) {  // alpha rides on the bottleneck job: its row of tiles follows the 8 x 9 main tiles
+        prod_tile0[11] = prod_tile0[8] + 8 * 9;
+        prod_n_in[11] = 9;
     }
     *total_tiles = tiles;
-    int wg = 0;
-    for (int j = 0; j < kNumJobs; ++j) {  // workgroups in proportion to the bytes a job streams
-        int n = (int)((double)(jb[j].x0_k + jb[j].y_k) / bytes * total_wgs + 0.5);
+    // largest-remainder split of exactly total_wgs workgroups (one more than the CU count would
+    // run alone after all the others)
+    int given = 0;
+    double frac[kNumJobs];
+    for (int j = 0; j < nj; ++j) {
+        const double share = (double)blocks[j] / bytes * total_wgs;
+        int n = (int)share;
         if (n < 1) n = 1;
-        jb[j].wg0 = wg, jb[j].wgs = n;
-        wg += n;
+        jb[j].wgs = n, frac[j] = share - n, given += n;
+    }
+    while (given < total_wgs) {
+        int best = 0;
+        for (int j = 1; j < nj; ++j)
+            if (frac[j] > frac[best]) best = j;
+        jb[best].wgs += 1, frac[best] -= 1.0, given += 1;
+    }
+    int wg = 0;
+    for (int j = 0; j < nj; ++j) {
+        jb[j].wg0 = wg;
+        wg += jb[j].wgs;
     }
 }
 
@@ -579,7 +716,7 @@ static int gperm_tiles() {
 using namespace nerf;
 
 #ifdef DW_STAMPS
-unsigned long long* g_dw_stamps = nullptr;
+static unsigned long long* g_dw_stamps = nullptr;
 NERF_API void nerf_debug_set_stamps(void* p) { g_dw_stamps = (unsigned long long*)p; }
 #endif
 
@@ -626,7 +763,8 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     int tiles;
     int wgs = 256;
     if (da.wave_tiles < 256 * 4) wgs = (int)(da.wave_tiles / 4 > kNumJobs ? da.wave_tiles / 4 : kNumJobs);
-    make_jobs(da.job, &tiles, wgs);
+    UnpackArgs ua{};
+    make_jobs(da.job, &tiles, wgs, ua.tile0, ua.n_in);
     hipError_t e = hipMemsetAsync(partial, 0, (size_t)tiles * 16 * 64 * sizeof(float), st);
     if (e != hipSuccess) return NERF_FAIL((int)e, "nerf_mlp_backward(memset): %s", hipGetErrorString(e));
     const int total_wgs = da.job[kNumJobs - 1].wg0 + da.job[kNumJobs - 1].wgs;
@@ -637,9 +775,7 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     rc = check_launch("nerf_mlp_backward(dw)");
     if (rc) return rc;
 
-    UnpackArgs ua{};
     ua.gperm = (const float*)partial, ua.inv_scale = 1.0f / gscale, ua.accumulate = accumulate;
-    for (int j = 0; j < kNumJobs; ++j) ua.tile0[j] = da.job[j].tile0, ua.n_in[j] = da.job[j].n_in;
     static const int dims[12][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
                                     {256, 256}, {256, 256}, {256, 256}, {283, 128}, {128, 3}, {256, 1}};
     for (int i = 0; i < 24; ++i) {
