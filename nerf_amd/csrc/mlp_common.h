@@ -1,6 +1,7 @@
-// Pieces shared by the fused MLP kernels (forward, training forward, backward chain): the
-// L2 -> LDS weight stream with its register prefetch pipeline, accumulator -> fragment
-// conversion, and the in-register positional encoding.  See mlp_layout.h for the data layout.
+// Pieces shared by the fused MLP kernels (forward, backward chain, weight gradients): the
+// L2 -> LDS weight stream with its register prefetch pipeline, counted vector-memory waits,
+// direct-to-LDS loads and the range reduction of the positional encoding.  Data layouts:
+// mlp_layout_wide.h (forward), mlp_layout.h (training).
 #pragma once
 #include <type_traits>
 #include "common.h"
@@ -96,12 +97,8 @@ DEV f32x16 mfma(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-DEV void glds16(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-// The same load issued from inline asm, so that the compiler does not know about it: where LDS
+// 16 bytes per lane, global memory -> LDS, issued from inline asm so that the compiler does not
+// know about it (the builtin form makes it drain lgkmcnt / vmcnt to zero): where LDS
 // addresses are not compile-time constants it cannot tell later LDS reads from loads still in
 // flight and would drain the whole queue (s_waitcnt vmcnt(0)) before every read.  The caller
 // owns the ordering: a counted s_waitcnt vmcnt, then a barrier if other waves read the data.
@@ -215,32 +212,6 @@ struct Stream {
     }
 };
 
-// The 32 values of tile T of an accumulator-ordered fp32 table in LDS (`table` already offset by
-// the lane half's 64 bytes): four broadcast reads.
-template <int T>
-DEV f32x16 load_bias_tile(const char* table) {
-    const f32x4* p = (const f32x4*)(table + T * 128);
-    const f32x4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-    return f32x16{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3],
-                  q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
-}
-
-// Registers 8*S..8*S+7 of an accumulator tile -> one fp16 B fragment (round to nearest even),
-// clamped to the fp16 range; RELU folds the activation into the clamp (one v_med3_f32).
-template <int S, bool RELU>
-DEV half8 to_frag(const f32x16& v) {
-    half8 out;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const float lo = RELU ? 0.f : -65504.f;
-        f32x2 x = {__builtin_amdgcn_fmed3f(v[8 * S + j], lo, 65504.f),
-                   __builtin_amdgcn_fmed3f(v[8 * S + j + 1], lo, 65504.f)};
-        half2v p = __builtin_convertvector(x, half2v);
-        out[j] = p[0], out[j + 1] = p[1];
-    }
-    return out;
-}
-
 // x / (2 pi) reduced to about [-0.5, 0.5] revolutions with a two-term constant, so that the
 // hardware sin/cos (which take revolutions) see a small argument whatever the magnitude of x.
 DEV float to_revolutions(float x) {
@@ -253,28 +224,6 @@ DEV float to_revolutions(float x) {
 DEV float double_revolutions(float f) {
     const float g = f + f;  // exact
     return g - rintf(g);    // exact
-}
-
-// Local encoding slots of this lane half: NF frequencies starting at 1 (h = 0) or
-// base_freq_h1 (h = 1); see pe_feature / view_feature in mlp_layout.h for the slot order.
-template <int NF, int NSLOT>
-DEV void encode(const float (&x)[3], int h, float base_freq_h1, float (&v)[NSLOT]) {
-    v[0] = h ? x[2] : x[0];
-    v[1] = h ? 0.f : x[1];
-    float f[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) f[c] = to_revolutions(h ? x[c] * base_freq_h1 : x[c]);
-#pragma unroll
-    for (int a = 0; a < NF; ++a) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v[2 + 6 * a + c] = __builtin_amdgcn_sinf(f[c]);
-            v[2 + 6 * a + 3 + c] = __builtin_amdgcn_cosf(f[c]);
-            f[c] = double_revolutions(f[c]);
-        }
-    }
-#pragma unroll
-    for (int i = 2 + 6 * NF; i < NSLOT; ++i) v[i] = 0.f;
 }
 
 template <int NSLOT>

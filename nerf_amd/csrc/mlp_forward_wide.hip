@@ -30,6 +30,7 @@ struct FwdWideArgs {
     const float* pts;       // MODE 1: [M,3]
     const float* viewdirs;  // MODE 1: [M/S,3]
     float4* raw;            // [M] (r,g,b,sigma)
+    char* act;              // training: saved activations [ceil(M/256)*8][kActBlocks][1 KiB], else null
     int64_t M;              // points
     int S;                  // points per ray
 };
@@ -49,17 +50,63 @@ struct WidePipe {
     f32x4 acc[2][2];    // [tile parity][point tile]
 };
 
+// Where a training forward saves its fragments: [wave tile][block][lane] (inference: unused).
+// Streamed (nt) stores: the saved tensors are read once, by other kernels, and must not displace
+// the weight stream from L2 (measured write rate of the kernel: 4.1 TB/s with nt, 3.5 with sc1,
+// 3.2 with the default policy).  Stores are counted in the wave's vector-memory queue.
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+struct WSink {
+    char* base;  // this lane's address inside block 0 of its wave tile
+    VmQueue* vm;
+    template <int BLK, class V>
+    DEV void put(const V& v) const {
+        __builtin_nontemporal_store(v, (V*)(base + BLK * kFragBytes));
+        vm->issued += 1;
+    }
+};
+
+// 16-byte register load issued from inline asm and counted in the wave's vector-memory queue (a
+// load the compiler knows about would make it wait for vmcnt(0), i.e. for the whole weight stream
+// and every pending store, before the first use).  The training forward uses it to fetch its own
+// saved encodings back shortly before the layers that need them, instead of holding 24
+// registers through the whole network.
+struct FragLoad {
+    half8 v;
+    int mark;
+    // wave-uniform base (scalar registers) + 32-bit per-lane byte offset: no 64-bit address to keep
+    DEV void issue(VmQueue& vm, const void* base, unsigned lane_off) {
+        const uint64_t b = (uint64_t)(uintptr_t)base;
+        const void* uniform_base = (const void*)(uintptr_t)(
+            ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+            (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b));
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane_off), "s"(uniform_base) : "memory");
+        vm.issued += 1;
+        mark = vm.issued;
+    }
+    DEV half8 get(const VmQueue& vm) {
+        vm.wait_until(mark);
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+};
+
 // What happens to a finished pair of accumulators (one output tile, both point tiles): four
 // slices, each two registers of one point tile -> one packed dword.
 struct WNoPrev {
     static constexpr bool kActive = false;
     template <int S> DEV void slice(const f32x4 (&)[2]) const {}
 };
-// Tile number TL inside its layer: tiles 2s, 2s+1 fill the low / high half of fragment s.
-template <bool RELU, int TL>
+// Tile number TL inside its layer (of NT): tiles 2s, 2s+1 fill the low / high half of fragment s.
+// STORE: a finished fragment s of point tile pt is saved as block ABLK + 2s + pt, and for
+// MBLK >= 0 the layer's ReLU mask bits are collected in mk[] and saved as block MBLK after the
+// last tile: dword 2 pt + (TL >> 3) of the lane, bit 4 (TL & 7) + r = register r of tile TL > 0,
+// i.e. unit 16 TL + 4 (lane >> 4) + r of point 16 pt + (lane & 15).
+template <bool RELU, int TL, bool STORE = false, int ABLK = 0, int MBLK = -1, int NT = 0>
 struct WToFrag {
     static constexpr bool kActive = true;
     half8* dst0;  // fragment array of point tile 0, point tile 1 follows at +kStride
+    WSink sink;
+    unsigned* mk;
     static constexpr int kStride = 8;
     template <int S> DEV void slice(const f32x4 (&v)[2]) const {
         constexpr int pt = S >> 1, q = S & 1;
@@ -70,6 +117,17 @@ struct WToFrag {
         half8& f = dst0[pt * kStride + (TL >> 1)];
         constexpr int e = 4 * (TL & 1) + 2 * q;
         f[e] = p[0], f[e + 1] = p[1];
+        if constexpr (STORE) {
+            if constexpr (MBLK >= 0) {
+                const unsigned pw = __builtin_bit_cast(unsigned, p);
+                const unsigned bits = ((pw & 0xFFFFu) ? 1u : 0u) | ((pw >> 16) ? 2u : 0u);
+                constexpr int sh = 4 * (TL & 7) + 2 * q, w = 2 * pt + (TL >> 3);
+                if constexpr (sh == 0) mk[w] = bits; else mk[w] |= bits << sh;
+            }
+            if constexpr ((TL & 1) == 1 && q == 1) sink.template put<ABLK + 2 * (TL >> 1) + pt>(f);
+            if constexpr (MBLK >= 0 && TL == NT - 1 && S == 3)
+                sink.template put<MBLK>(uint4v{mk[0], NT > 8 ? mk[1] : 0u, mk[2], NT > 8 ? mk[3] : 0u});
+        }
     }
 };
 struct WKeepRow0 {
@@ -114,14 +172,14 @@ DEV void wide_tile(WidePipe& p, GetB&& getB, const Prev& prev) {
 // One layer of NT output tiles of NK k-steps; its output becomes fragments 0..NT/2-1 of `out`
 // (both point tiles).  `before` finishes the tile that preceded the layer; the returned object
 // finishes the layer's last tile.
-template <int F0, int NT, int NK, int T0, bool RELU, class GetB, class Prev>
-DEV auto wide_layer(WidePipe& p, half8* out, GetB&& getB, const Prev& before) {
+template <int F0, int NT, int NK, int T0, bool RELU, bool STORE, int ABLK, int MBLK, class GetB, class Prev>
+DEV auto wide_layer(WidePipe& p, const WSink& sink, unsigned* mk, half8* out, GetB&& getB, const Prev& before) {
     wide_tile<F0, NK, T0>(p, getB, before);
     static_for<1, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        wide_tile<F0 + t * NK, NK, T0 + t>(p, getB, WToFrag<RELU, t - 1>{out});
+        wide_tile<F0 + t * NK, NK, T0 + t>(p, getB, WToFrag<RELU, t - 1, STORE, ABLK, MBLK, NT>{out, sink, mk});
     });
-    return WToFrag<RELU, NT - 1>{out};
+    return WToFrag<RELU, NT - 1, STORE, ABLK, MBLK, NT>{out, sink, mk};
 }
 
 // Local encoding slots of lane group g for a point: see lw::pe_feature.
@@ -169,7 +227,7 @@ DEV void encode_view(const float (&x)[3], int g, half8 (&out)[1]) {
     pack_slots<8>(v, out);
 }
 
-template <int MODE>
+template <int MODE, bool STORE>
 __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[kWRingBytes + lw::kBiasBytes];
     const int lane = threadIdx.x & 63;
@@ -187,14 +245,10 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     // ---- this lane's two query points (one per point tile) and their view directions ----
     constexpr int kS = 8;  // fragments (k-steps of 32 features) per point tile in a set
     half8 fa[2 * kS], fb[2 * kS], pe[2][2], vpe[2][1];
-    int64_t pidx[2];
-    bool valid[2];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (lane & 15);
-        pidx[pt] = p;
-        valid[pt] = p < a.M;
-        const int64_t pc = valid[pt] ? p : a.M - 1;
+        const int64_t pc = p < a.M ? p : a.M - 1;
         const int64_t ray = pc / a.S;
         float x[3], vd[3];
         if (MODE == 0) {
@@ -216,6 +270,24 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
         encode_view(vd, g, vpe[pt]);
     }
 
+    WSink sink{nullptr, &vm};
+    const char* act_tile = nullptr;  // this wave's tile of saved activations (wave-uniform)
+    if constexpr (STORE) {
+        const int64_t wave_tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+        act_tile = a.act + (size_t)wave_tile * kActBlocks * kFragBytes;
+        sink.base = a.act + (size_t)wave_tile * kActBlocks * kFragBytes + lane * 16;
+        static_for<0, 2>([&](auto sc) {
+            constexpr int k = decltype(sc)::value;
+            sink.template put<A_PE + 2 * k>(pe[0][k]);
+            sink.template put<A_PE + 2 * k + 1>(pe[1][k]);
+        });
+        sink.template put<A_VPE>(vpe[0][0]);
+        sink.template put<A_VPE + 1>(vpe[1][0]);
+    }
+    const int enc_saved = vm.issued;  // the saved encodings are in memory once the queue is past this mark
+    FragLoad lpe[4], lvpe[2];
+    unsigned mk[4] = {0u, 0u, 0u, 0u};
+
     auto from_pe = [&](auto pt, auto kc) { return pe[decltype(pt)::value][decltype(kc)::value]; };
     auto from_a = [&](auto pt, auto kc) { return fa[decltype(pt)::value * kS + decltype(kc)::value]; };
     auto from_b = [&](auto pt, auto kc) { return fb[decltype(pt)::value * kS + decltype(kc)::value]; };
@@ -227,41 +299,61 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
         const f32x4 b = *(const f32x4*)(pp.bias);
         pp.acc[0][0] = b, pp.acc[0][1] = b;
     }
-    auto c0 = wide_layer<lw::F_L0, 16, 2, lw::T_L0, true>(pp, fa, from_pe, WNoPrev{});                    // layer 0
-    auto c1 = wide_layer<lw::F_L1 + 0 * 128, 16, 8, lw::T_L1 + 0, true>(pp, fb, from_a, c0);             // layers 1..4
-    auto c2 = wide_layer<lw::F_L1 + 1 * 128, 16, 8, lw::T_L1 + 16, true>(pp, fa, from_b, c1);
-    auto c3 = wide_layer<lw::F_L1 + 2 * 128, 16, 8, lw::T_L1 + 32, true>(pp, fb, from_a, c2);
-    auto c4 = wide_layer<lw::F_L1 + 3 * 128, 16, 8, lw::T_L1 + 48, true>(pp, fa, from_b, c3);
-    auto c5 = wide_layer<lw::F_L5, 16, 10, lw::T_L5, true>(pp, fb, [&](auto pt, auto kc) {               // layer 5: [PE ; h]
+    auto c0 = wide_layer<lw::F_L0, 16, 2, lw::T_L0, true, STORE, A_H0, A_MASK + 0>(pp, sink, mk, fa, from_pe, WNoPrev{});                     // layer 0
+    auto c1 = wide_layer<lw::F_L1 + 0 * 128, 16, 8, lw::T_L1 + 0, true, STORE, A_H0 + 16, A_MASK + 1>(pp, sink, mk, fb, from_a, c0);        // layers 1..4
+    auto c2 = wide_layer<lw::F_L1 + 1 * 128, 16, 8, lw::T_L1 + 16, true, STORE, A_H0 + 32, A_MASK + 2>(pp, sink, mk, fa, from_b, c1);
+    auto c3 = wide_layer<lw::F_L1 + 2 * 128, 16, 8, lw::T_L1 + 32, true, STORE, A_H0 + 48, A_MASK + 3>(pp, sink, mk, fb, from_a, c2);
+    if constexpr (STORE) {  // the point encoding comes back during layer 4 (blocks A_PE + 2k + pt)
+        vm.wait_until(enc_saved);
+        static_for<0, 4>([&](auto ic) { lpe[decltype(ic)::value].issue(vm, act_tile + (A_PE + decltype(ic)::value) * kFragBytes, lane * 16); });
+    }
+    auto c4 = wide_layer<lw::F_L1 + 3 * 128, 16, 8, lw::T_L1 + 48, true, STORE, A_H0 + 64, A_MASK + 4>(pp, sink, mk, fa, from_b, c3);
+    half8 pe5[2][2];
+    static_for<0, 4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, k = i >> 1, pt = i & 1;
+        if constexpr (STORE) pe5[pt][k] = lpe[i].get(vm); else pe5[pt][k] = pe[pt][k];
+    });
+    auto c5 = wide_layer<lw::F_L5, 16, 10, lw::T_L5, true, STORE, A_H0 + 80, A_MASK + 5>(pp, sink, mk, fb, [&](auto pt, auto kc) {         // layer 5: [PE ; h]
         constexpr int k = decltype(kc)::value;
-        if constexpr (k < 2) return pe[decltype(pt)::value][k]; else return fa[decltype(pt)::value * kS + k - 2];
+        if constexpr (k < 2) return pe5[decltype(pt)::value][k]; else return fa[decltype(pt)::value * kS + k - 2];
     }, c4);
-    auto c6 = wide_layer<lw::F_L6 + 0 * 128, 16, 8, lw::T_L6 + 0, true>(pp, fa, from_b, c5);             // layers 6, 7
-    auto c7 = wide_layer<lw::F_L6 + 1 * 128, 16, 8, lw::T_L6 + 16, true>(pp, fb, from_a, c6);
+    auto c6 = wide_layer<lw::F_L6 + 0 * 128, 16, 8, lw::T_L6 + 0, true, STORE, A_H0 + 96, A_MASK + 6>(pp, sink, mk, fa, from_b, c5);        // layers 6, 7
+    auto c7 = wide_layer<lw::F_L6 + 1 * 128, 16, 8, lw::T_L6 + 16, true, STORE, A_H0 + 112, A_MASK + 7>(pp, sink, mk, fb, from_a, c6);
     // alpha head (row 0 of its tile), then the bottleneck (linear)
     float sigma[2];
     wide_tile<lw::F_ALPHA, 8, lw::T_ALPHA>(pp, from_b, c7);
-    auto c8 = wide_layer<lw::F_BOTT, 16, 8, lw::T_BOTT, false>(pp, fa, from_b, WKeepRow0{sigma});
+    if constexpr (STORE) {  // the view encoding comes back during the bottleneck layer
+        lvpe[0].issue(vm, act_tile + A_VPE * kFragBytes, lane * 16);
+        lvpe[1].issue(vm, act_tile + (A_VPE + 1) * kFragBytes, lane * 16);
+    }
+    auto c8 = wide_layer<lw::F_BOTT, 16, 8, lw::T_BOTT, false, STORE, A_BOTT, -1>(pp, sink, mk, fa, from_b, WKeepRow0{sigma});
+    half8 vpe9[2];
+    if constexpr (STORE) vpe9[0] = lvpe[0].get(vm), vpe9[1] = lvpe[1].get(vm); else vpe9[0] = vpe[0][0], vpe9[1] = vpe[1][0];
     // view layer: [bottleneck ; view PE] -> 128, relu
-    auto c9 = wide_layer<lw::F_VIEW, 8, 9, lw::T_VIEW, true>(pp, fb, [&](auto pt, auto kc) {
+    auto c9 = wide_layer<lw::F_VIEW, 8, 9, lw::T_VIEW, true, STORE, A_V, A_MASK + 8>(pp, sink, mk, fb, [&](auto pt, auto kc) {
         constexpr int k = decltype(kc)::value;
-        if constexpr (k < 8) return fa[decltype(pt)::value * kS + k]; else return vpe[decltype(pt)::value][0];
+        if constexpr (k < 8) return fa[decltype(pt)::value * kS + k]; else return vpe9[decltype(pt)::value];
     }, c8);
     wide_tile<lw::F_RGB, 4, lw::T_RGB>(pp, from_b, c9);                                                  // rgb rows 0..2
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const f32x4& c = pp.acc[lw::T_RGB & 1][pt];
-        if (valid[pt] && g == 0) a.raw[pidx[pt]] = make_float4(c[0], c[1], c[2], sigma[pt]);
+        // the lane id is read afresh: neither it nor the point index is worth registers through the network
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (ln & 15);
+        if (p < a.M && (ln >> 4) == 0) a.raw[p] = make_float4(c[0], c[1], c[2], sigma[pt]);
     }
 }
 
 static int launch_fwd_wide(const FwdWideArgs& a, int mode, hipStream_t st, const char* what) {
     const int64_t blocks = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
     if (blocks > 0x7fffffffLL) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: too many points (%lld)", what, (long long)a.M);
-    if (mode == 0)
-        mlp_fwd_wide_kernel<0><<<(unsigned)blocks, 512, 0, st>>>(a);
+    if (a.act)
+        mlp_fwd_wide_kernel<0, true><<<(unsigned)blocks, 512, 0, st>>>(a);
+    else if (mode == 0)
+        mlp_fwd_wide_kernel<0, false><<<(unsigned)blocks, 512, 0, st>>>(a);
     else
-        mlp_fwd_wide_kernel<1><<<(unsigned)blocks, 512, 0, st>>>(a);
+        mlp_fwd_wide_kernel<1, false><<<(unsigned)blocks, 512, 0, st>>>(a);
     return check_launch(what);
 }
 
@@ -295,4 +387,24 @@ NERF_API int nerf_mlp_forward_pts(const void* packed, const float* pts, const fl
     a.packed = (const char*)packed, a.pts = pts, a.viewdirs = viewdirs;
     a.raw = (float4*)raw, a.M = n * S, a.S = S;
     return launch_fwd_wide(a, 1, as_stream(stream), "nerf_mlp_forward_pts");
+}
+
+NERF_API size_t nerf_mlp_act_bytes(int64_t n_points) {
+    const int64_t wave_tiles = (n_points + kPointsPerBlock - 1) / kPointsPerBlock * kWavesPerBlock;
+    return (size_t)wave_tiles * layout::kActBlocks * layout::kFragBytes;
+}
+
+NERF_API int nerf_mlp_forward_train(const void* packed, const float* rays, int width, const float* z,
+                                    int64_t n_rays, int S, float* raw, void* act,
+                                    nerf_stream_t stream) {
+    NERF_REQUIRE(packed && rays && z && raw && act, "nerf_mlp_forward_train: null pointer");
+    NERF_REQUIRE(width >= 11, "nerf_mlp_forward_train: ray batch needs view directions (width >= 11, got %d)", width);
+    NERF_REQUIRE(n_rays >= 0 && S > 0, "nerf_mlp_forward_train: bad size");
+    NERF_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0 && ((uintptr_t)act & 15) == 0,
+                 "nerf_mlp_forward_train: packed, raw and act must be 16-byte aligned");
+    if (n_rays == 0) return 0;
+    FwdWideArgs a{};
+    a.packed = (const char*)packed, a.rays = rays, a.z = z, a.width = width;
+    a.raw = (float4*)raw, a.act = (char*)act, a.M = n_rays * S, a.S = S;
+    return launch_fwd_wide(a, 0, as_stream(stream), "nerf_mlp_forward_train");
 }

@@ -20,6 +20,7 @@
 //     1.19 MFLOP/point.
 //  3. mlp_grad_unpack_kernel -- accumulator-ordered partial sums -> the 24 arrays, times 1/gscale.
 #include "mlp_common.h"
+#include "mlp_layout_wide.h"
 
 namespace nerf {
 
@@ -79,15 +80,24 @@ static_assert(kBwdLds <= 160 * 1024, "LDS budget");
 typedef short short8 __attribute__((ext_vector_type(8)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
-// 16-byte load into registers issued from inline asm and counted in the VmQueue like the weight
-// stream's loads (a load the compiler knows about would make it wait for vmcnt(0), i.e. for the
-// whole stream and every pending store, before the first use).
+// The ReLU mask bits of one layer for this lane's point, loaded by inline asm and counted in the
+// VmQueue like the weight stream's loads (a load the compiler knows about would make it wait for
+// vmcnt(0), i.e. for the whole stream and every pending store, before the first use).
+// The forward (16x16x32 tiles: lane = point & 15 + 16 g, g = 0..3) saved, per lane, dwords
+// [point tile][2]: bit 4 (t & 7) + r of dword t >> 3 = unit 16 t + 4 g + r.  A lane of this kernel
+// (32x32x16 tiles: point = lane & 31, half h) holds units with (unit >> 2) & 1 == h, i.e. the
+// pieces g = h and g = h + 2 of its point: two 8-byte loads, v[0:1] and v[2:3].
 struct MaskLoad {
     uint4v v;
     int mark;
-    DEV void issue(VmQueue& vm, const void* g) {
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(g) : "memory");
-        vm.issued += 1;
+    DEV void issue(VmQueue& vm, const char* block, int lane) {
+        const int p = lane & 15, pt = (lane >> 4) & 1, h = lane >> 5;
+        const char* g0 = block + 16 * (p + 16 * h) + 8 * pt;
+        unsigned long long lo, hi;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(lo) : "v"(g0) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(hi) : "v"(g0 + 16 * 32) : "memory");
+        v = uint4v{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+        vm.issued += 2;
         mark = vm.issued;
     }
     // The loaded value; every use is ordered behind the counted wait.
@@ -134,14 +144,16 @@ struct CToFrags {
     static constexpr bool kActive = true;
     half8* dst;   // the layer's fragment set
     GradSink sink;
-    uint4v mk;    // the layer's mask bits (see A_MASK in mlp_layout.h)
+    uint4v mk;    // the layer's mask bits for this lane's point (see MaskLoad)
     template <int S> DEV void slice(const f32x16& v) const {
         const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * S], -65504.f, 65504.f),
                          __builtin_amdgcn_fmed3f(v[2 * S + 1], -65504.f, 65504.f)};
         half2v p = __builtin_convertvector(x, half2v);
         if constexpr (MASKED) {
-            constexpr int sh = 16 * (TL & 1) + 2 * S;
-            const unsigned w = mk[TL >> 1] >> sh;
+            // registers 2S, 2S+1 of 32-unit tile TL = units 16 t + 4 g + r with t = 2 TL + (S >> 2),
+            // g = h + 2 ((S >> 1) & 1), r = 2 S & 3 (+1): see MaskLoad
+            constexpr int t = 2 * TL + (S >> 2), piece = (S >> 1) & 1, sh = 4 * (t & 7) + ((2 * S) & 3);
+            const unsigned w = mk[2 * piece + (t >> 3)] >> sh;
             const unsigned keep = ((w & 1u) ? 0x0000FFFFu : 0u) | ((w & 2u) ? 0xFFFF0000u : 0u);
             p = __builtin_bit_cast(half2v, __builtin_bit_cast(unsigned, p) & keep);
         }
@@ -196,10 +208,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
     VmQueue vm;
     BwdStream st(vm, a.packed_bwd, lds, wave, lane);
     st.prologue();
-    const char* masks = a.act + ((size_t)wave_tile * kActBlocks + A_MASK) * kFragBytes + lane * 16;
+    const char* masks = a.act + ((size_t)wave_tile * kActBlocks + A_MASK) * kFragBytes;
     MaskLoad mv, m7, m6, m5, m4, m3, m2, m1, m0;
-    mv.issue(vm, masks + 8 * kFragBytes);
-    m7.issue(vm, masks + 7 * kFragBytes);
+    mv.issue(vm, masks + 8 * kFragBytes, lane);
+    m7.issue(vm, masks + 7 * kFragBytes, lane);
     GradSink sink{a.gbuf + (size_t)wave_tile * kGradBlocks * kFragBytes + lane * 16, &vm};
 
     const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + (lane & 31);
@@ -225,23 +237,23 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
     st.start();
     // each layer's mask bits are requested one layer before they are needed
     auto c0 = chain_layer<B_V, 4, 1, true, G_DV>(pp, sink, mv.get(vm), fa, [&](auto) { return dC; }, CNoPrev{});   // d v_pre
-    m6.issue(vm, masks + 6 * kFragBytes);
+    m6.issue(vm, masks + 6 * kFragBytes, lane);
     auto c1 = chain_layer<B_BOTT, 8, 8, false, G_DBOTT>(pp, sink, none, fb, from_a, c0);                           // d bott
     auto c2 = chain_layer<B_H7, 8, 17, true, G_DPRE0 + 16 * 7>(pp, sink, m7.get(vm), fa, [&](auto kc) {            // d pre7
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 16) return fb[k]; else return dA;
     }, c1);
-    m5.issue(vm, masks + 5 * kFragBytes);
+    m5.issue(vm, masks + 5 * kFragBytes, lane);
     auto c3 = chain_layer<B_H6 + 0 * 128, 8, 16, true, G_DPRE0 + 16 * 6>(pp, sink, m6.get(vm), fb, from_a, c2);    // d pre6
-    m4.issue(vm, masks + 4 * kFragBytes);
+    m4.issue(vm, masks + 4 * kFragBytes, lane);
     auto c4 = chain_layer<B_H6 + 1 * 128, 8, 16, true, G_DPRE0 + 16 * 5>(pp, sink, m5.get(vm), fa, from_b, c3);    // d pre5
-    m3.issue(vm, masks + 3 * kFragBytes);
+    m3.issue(vm, masks + 3 * kFragBytes, lane);
     auto c5 = chain_layer<B_H6 + 2 * 128, 8, 16, true, G_DPRE0 + 16 * 4>(pp, sink, m4.get(vm), fb, from_a, c4);    // d pre4
-    m2.issue(vm, masks + 2 * kFragBytes);
+    m2.issue(vm, masks + 2 * kFragBytes, lane);
     auto c6 = chain_layer<B_H6 + 3 * 128, 8, 16, true, G_DPRE0 + 16 * 3>(pp, sink, m3.get(vm), fa, from_b, c5);    // d pre3
-    m1.issue(vm, masks + 1 * kFragBytes);
+    m1.issue(vm, masks + 1 * kFragBytes, lane);
     auto c7 = chain_layer<B_H6 + 4 * 128, 8, 16, true, G_DPRE0 + 16 * 2>(pp, sink, m2.get(vm), fb, from_a, c6);    // d pre2
-    m0.issue(vm, masks + 0 * kFragBytes);
+    m0.issue(vm, masks + 0 * kFragBytes, lane);
     auto c8 = chain_layer<B_H6 + 5 * 128, 8, 16, true, G_DPRE0 + 16 * 1>(pp, sink, m1.get(vm), fa, from_b, c7);    // d pre1
     auto c9 = chain_layer<B_H6 + 6 * 128, 8, 16, true, G_DPRE0 + 16 * 0>(pp, sink, m0.get(vm), fb, from_a, c8);    // d pre0
     static_for<0, 8>([&](auto sc) { c9.template slice<decltype(sc)::value>(pp.acc[1]); });
@@ -283,14 +295,19 @@ struct DwArgs {
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 // LDS image of one 32-feature tile (a pair of stored blocks) of a staged wave tile: 2 KiB laid
-// out [point][block of the pair][lane half][8 features], 64 B per point, so that the 32 lanes
-// of a half-wave, which read 4 points x 64 B with one transposing read, touch every bank once.
-// The direct-to-LDS load writes lane-linear, so the permutation is applied to the SOURCE
-// address: LDS lane L of load n (n = 0, 1) fetches point 16n + L/4, block (L>>1)&1, half L&1.
+// out [point][4 granules][8 features], 64 B per point, so that the 32 lanes of a half-wave,
+// which read 4 points x 64 B with one transposing read, touch every bank once.  Feature slot
+// 8 * granule + element of the image becomes row (or column) 8 * granule + element of the
+// 32 x 32 product.  The direct-to-LDS load writes lane-linear, so the permutation is applied to
+// the SOURCE address: LDS lane L of load n (n = 0, 1) fetches point 16n + L/4, granule L & 3.
+//  - gradient pairs (32x32x16 fragments of the chain kernel: block = 16 features, lane = point
+//    + 32 half): granule = 2 (block of the pair) + half;
+//  - input pairs (16x16x32 fragments of the forward kernel: block = one 16-point tile x 32
+//    features, lane = point + 16 g): granule = g, and load n reads block n.
 constexpr int kTileImgBytes = 2 * kFragBytes;
 
-// Per-lane byte offset of a tile-image load inside its pair of stored blocks (load n = 0, 1 of
-// the image adds 256 n bytes, which the caller folds into the wave-uniform base address).
+// Per-lane byte offset of a gradient-image load inside its pair of stored blocks (load n = 0, 1
+// of the image adds 256 n bytes, which the caller folds into the wave-uniform base address).
 DEV unsigned stage_lane_offset(int lane, bool one_block) {
     const int c = lane >> 2, sb = one_block ? 0 : (lane >> 1) & 1, hh = lane & 1;
     return (unsigned)(sb * kFragBytes + (32 * hh + c) * 16);
@@ -322,7 +339,8 @@ struct DwStageSrc {
     int x0_blk, x1_blk, y_blk, y1_blk;
     bool y_one;
     int64_t t_lo, t_hi;
-    unsigned off_two, off_one;  // per-lane offsets: two-block / one-block tile images
+    unsigned off_two, off_one;  // per-lane offsets of gradient images: two-block / one-block
+    unsigned off_x;             // per-lane offset of input images
 };
 
 template <int NX0, int NX1, int NY, int NY1, int G>
@@ -359,8 +377,10 @@ DEV void dw_stage_in(const DwStageSrc s, int64_t group, char* dst, int wave) {
 #pragma unroll
         for (int k = 1; k < G; ++k)
             if (gt == k) ab = abase[k], gb = gbase[k];
-        const char* src = (is_x ? ab : gb) + (unsigned)(blk * kFragBytes + n * 256);
-        glds16_untracked_sbase<true>(src, one ? s.off_one : s.off_two, dst + (unsigned)(u * kFragBytes));
+        // load n of an image = points 16 n .. 16 n + 15: block n of an input pair (one point tile
+        // per block), the second 256 bytes of each lane half of a gradient pair
+        const char* src = (is_x ? ab : gb) + (unsigned)(blk * kFragBytes + n * (is_x ? kFragBytes : 256));
+        glds16_untracked_sbase<true>(src, is_x ? s.off_x : one ? s.off_one : s.off_two, dst + (unsigned)(u * kFragBytes));
     }
 }
 
@@ -400,7 +420,8 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
     const int64_t nstage = (ntile + G - 1) / G;
 
     const DwStageSrc src{a.act, a.gbuf, jb.x0_blk, jb.x1_blk, jb.y_blk, jb.y1_blk, y_one, t_lo, t_hi,
-                         stage_lane_offset(lane, false), stage_lane_offset(lane, true)};
+                         stage_lane_offset(lane, false), stage_lane_offset(lane, true),
+                         (unsigned)((lane & 3) * 256 + (lane >> 2) * 16)};
     auto stage_in = [=](int64_t group, int sbuf) {
         dw_stage_in<NX0, NX1, NY, NY1, G>(src, group, lds + sbuf * kDwStageBytes, wave);
     };
@@ -595,26 +616,35 @@ struct UnpackArgs {
 __device__ const int kLayerDims[12][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
                                           {256, 256}, {256, 256}, {256, 256}, {283, 128}, {128, 3}, {256, 1}};
 
-// Slot (tile, row) of feature f of a 256- or 128-wide activation in fragment order.
+// Slot (tile, row) of OUTPUT feature f of a 256- or 128-wide layer in the chain kernel's gradient
+// fragments (layout::acc_feature).
 __device__ __forceinline__ void acc_slot(int f, int& tile, int& row) {
     const int s = 2 * (f >> 5) + ((f >> 4) & 1), f16 = f & 15;
     const int h = (f16 >> 2) & 1, j = ((f16 >> 3) << 2) | (f16 & 3);
     tile = s >> 1, row = 16 * (s & 1) + 8 * h + j;
 }
 
-// Slot of feature f of an encoding (nfreq_per_half frequencies per lane half).
-__device__ __forceinline__ void enc_slot(int f, int nfreq_per_half, int& tile, int& row) {
-    int h, idx;
-    if (f == 0) h = 0, idx = 0;
-    else if (f == 1) h = 0, idx = 1;
-    else if (f == 2) h = 1, idx = 0;
-    else {
-        const int q = (f - 3) / 6, b = (f - 3) % 6;
-        h = q / nfreq_per_half;
-        idx = 2 + 6 * (q % nfreq_per_half) + b;
-    }
-    const int s = idx >> 3, j = idx & 7;
-    tile = s >> 1, row = 16 * (s & 1) + 8 * h + j;
+// Slot (tile, row) of INPUT feature f of a saved 256- or 128-wide activation (the forward
+// kernel's fragments, lw::acc_feature: element j of lane group g of k-step s is feature
+// 32 s + 16 (j >> 2) + 4 g + (j & 3)); row = 8 g + j.
+__device__ __forceinline__ void in_slot(int f, int& tile, int& row) {
+    const int f32 = f & 31, g = (f32 >> 2) & 3, j = 4 * (f32 >> 4) + (f32 & 3);
+    tile = f >> 5, row = 8 * g + j;
+}
+
+// Slot of feature f of the saved point encoding (lw::pe_feature: 16 local slots per lane group,
+// two k-steps) / of the saved view encoding (lw::view_feature: 8 local slots, one k-step).
+__device__ __forceinline__ void pe_slot(int f, int& tile, int& row) {
+    tile = 0, row = 0;
+    for (int g = 0; g < 4; ++g)
+        for (int i = 0; i < 16; ++i)
+            if (lw::pe_feature(g, i) == f) tile = i >> 3, row = 8 * g + (i & 7);
+}
+__device__ __forceinline__ void view_slot(int f, int& tile, int& row) {
+    tile = 0, row = 0;
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < 8; ++j)
+            if (lw::view_feature(g, j) == f) row = 8 * g + j;
 }
 
 // One thread per parameter scalar of the whole network.  pi = parameter array (get_weights
@@ -635,12 +665,12 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
     if (layer == 10 || layer == 11) ot = 0, orow = out;           // d rgb slots 0..2 / d alpha slot 0
     else acc_slot(out, ot, orow);
     if (is_bias) it = a.n_in[layer] - 1, irow = 0;
-    else if (layer == 0) enc_slot(in, 5, it, irow);
+    else if (layer == 0) pe_slot(in, it, irow);
     else if (layer == 5) {       // input tiles: h4 (8), then the point encoding (2)
-        if (in < 63) { enc_slot(in, 5, it, irow); it += 8; } else acc_slot(in - 63, it, irow);
+        if (in < 63) { pe_slot(in, it, irow); it += 8; } else in_slot(in - 63, it, irow);
     } else if (layer == 9) {     // input tiles: bottleneck (8), then the view encoding (1)
-        if (in < 256) acc_slot(in, it, irow); else { enc_slot(in - 256, 2, it, irow); it += 8; }
-    } else acc_slot(in, it, irow);
+        if (in < 256) in_slot(in, it, irow); else { view_slot(in - 256, it, irow); it += 8; }
+    } else in_slot(in, it, irow);
     const int job = layer;
     const int n_in = a.n_in[job];
     const int reg = (orow & 3) + 4 * (orow >> 3), lane = 32 * ((orow >> 2) & 1) + irow;

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _native.SIGNATURES, f"{name} has no ctypes signature in nerf_amd/_native.py"
     assert sorted(_native.SIGNATURES) == declared
     assert lib.nerf_abi_version() == 1
-    assert lib.nerf_mlp_packed_bytes() == 2 * (74 * 16384 + 10 * 1024)
+    assert lib.nerf_mlp_packed_bytes() == 74 * 16384 + 10 * 1024
 
 
 def test_argument_errors_are_reported_without_a_gpu():
