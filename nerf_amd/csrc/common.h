@@ -32,13 +32,6 @@ inline hipStream_t as_stream(nerf_stream_t s) { return (hipStream_t)s; }
 
 constexpr int kWave = 64;
 
-// Sum / product across the 64 lanes of a wave; every lane gets the result.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_or(float old, float src) {
     return __builtin_bit_cast(
@@ -68,6 +61,14 @@ __device__ __forceinline__ float wave_scan_add(float v) {
     return v;
 }
 
+__device__ __forceinline__ float lane63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Sum across the 64 lanes of a wave; every lane gets the result (six DPP adds and one lane
+// read: no LDS traffic, unlike a butterfly of ds_bpermute).
+__device__ __forceinline__ float wave_sum(float v) { return lane63(wave_scan_add(v)); }
+
 // Lane i gets lane i-1's value; lane 0 gets `first`.
 __device__ __forceinline__ float wave_shr1(float first, float v) {
     return dpp_or<0x138, 0xf>(first, v);  // wave_shr:1
@@ -93,10 +94,6 @@ __device__ __forceinline__ float wave_rscan_add(float v) {
     const int row = (threadIdx.x & 63) >> 4;
     const float add = (row == 0) ? (t1 + t2) + t3 : (row == 1) ? t2 + t3 : (row == 2) ? t3 : 0.0f;
     return v + add;
-}
-
-__device__ __forceinline__ float lane63(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 }  // namespace nerf

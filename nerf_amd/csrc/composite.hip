@@ -8,6 +8,26 @@ namespace nerf {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// What a lane reads for one sample: raw, depth, the next depth and the density noise.
+struct SampleIn {
+    float4 r;
+    float zz, znext, nz;
+};
+
+__device__ __forceinline__ SampleIn load_sample(const float4* __restrict__ raw, const float* __restrict__ z,
+                                                const float* __restrict__ noise, int64_t row, int s, int S) {
+    SampleIn in;
+    const bool valid = s < S;
+    in.r = valid ? raw[row + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    in.zz = valid ? z[row + s] : 0.f;
+    in.znext = (s + 1 < S) ? z[row + s + 1] : 0.f;
+    in.nz = (noise && valid) ? noise[row + s] : 0.f;
+    return in;
+}
+
+// NCH = 64-sample chunks per ray, every load of the ray issued before the first scan (NCH x 1.3
+// KiB in flight per wave); NCH = 0: any S, chunk by chunk.
+template <int NCH>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float4* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d,
     int d_stride, int64_t n, int S, int white_bkgd, const float* __restrict__ noise,
@@ -17,21 +37,25 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t ray = wave0; ray < n; ray += nwaves) {
+        const int64_t row = ray * S;
+        SampleIn pre[NCH > 0 ? NCH : 1];
+        if constexpr (NCH > 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) pre[c] = load_sample(raw, z, noise, row, 64 * c + lane, S);
+        }
         const float dx = rays_d[ray * d_stride], dy = rays_d[ray * d_stride + 1],
                     dz = rays_d[ray * d_stride + 2];
         const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
-        const int64_t row = ray * S;
         float carry = 1.0f;
         float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
-        for (int base = 0; base < S; base += 64) {
+        auto chunk = [&](int base, const SampleIn& in) {
             const int s = base + lane;
             const bool valid = s < S;
-            float4 r = valid ? raw[row + s] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float zz = valid ? z[row + s] : 0.f;
-            float dist = (s + 1 < S) ? z[row + s + 1] - zz : 1e10f;
+            const float zz = in.zz;
+            float dist = (s + 1 < S) ? in.znext - zz : 1e10f;
             dist = dist * norm;
-            float sig = r.w;
-            if (noise) sig = sig + (valid ? noise[row + s] : 0.f) * noise_std;
+            float sig = in.r.w;
+            if (noise) sig = sig + in.nz * noise_std;
             const float alpha = valid ? 1.0f - __expf(-fmaxf(sig, 0.f) * dist) : 0.f;
             const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
             const float incl = wave_scan_mul(t);
@@ -40,12 +64,18 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             carry = carry * lane63(incl);
             if (valid) {
                 if (weights) weights[row + s] = w;
-                sr += w * sigmoidf(r.x);
-                sg += w * sigmoidf(r.y);
-                sb += w * sigmoidf(r.z);
+                sr += w * sigmoidf(in.r.x);
+                sg += w * sigmoidf(in.r.y);
+                sb += w * sigmoidf(in.r.z);
                 sd += w * zz;
                 sa += w;
             }
+        };
+        if constexpr (NCH > 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) chunk(64 * c, pre[c]);
+        } else {
+            for (int base = 0; base < S; base += 64) chunk(base, load_sample(raw, z, noise, row, base + lane, S));
         }
         sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sd = wave_sum(sd),
         sa = wave_sum(sa);
@@ -182,8 +212,16 @@ NERF_API int nerf_composite_fwd(const float* raw, const float* z, const float* r
     if (noise_std <= 0.f) noise = nullptr;
     const int64_t want = (n + 3) / 4;
     const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
-    composite_fwd_kernel<<<blocks, 256, 0, as_stream(stream)>>>(
-        (const float4*)raw, z, rays_d, d_stride, n, S, white_bkgd, noise, noise_std, rgb_map,
-        disp_map, acc_map, depth_map, weights);
+    auto launch = [&](auto kernel) {
+        kernel<<<blocks, 256, 0, as_stream(stream)>>>((const float4*)raw, z, rays_d, d_stride, n, S, white_bkgd, noise,
+                                                        noise_std, rgb_map, disp_map, acc_map, depth_map, weights);
+    };
+    const int nch = (S + 63) / 64;
+    if (nch == 1) launch(composite_fwd_kernel<1>);
+    else if (nch == 2) launch(composite_fwd_kernel<2>);
+    else if (nch == 3) launch(composite_fwd_kernel<3>);
+    else if (nch == 4) launch(composite_fwd_kernel<4>);
+    else if (nch <= 6) launch(composite_fwd_kernel<6>);
+    else launch(composite_fwd_kernel<0>);
     return check_launch("nerf_composite_fwd");
 }
