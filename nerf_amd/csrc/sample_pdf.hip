@@ -3,8 +3,9 @@
 // lane inverts the CDF for its own samples by binary search (searchsorted side='right'), and the
 // two sorted depth lists are merged by rank (each element's output slot = its own index + the
 // count of elements of the other list that precede it), so no general sort is needed when the
-// uniforms are the deterministic linspace.  With caller-supplied random uniforms the samples
-// are first sorted in LDS by a bitonic network.  HBM traffic: z and weights read once
+// uniforms are the deterministic linspace; a sample's rank then follows from the bin it was
+// drawn from, without a search.  With caller-supplied random uniforms the samples are first
+// sorted in LDS by a bitonic network.  Searches are fixed-length halving loops.  HBM traffic: z and weights read once
 // (coalesced), merged depths written once.
 #include "common.h"
 
@@ -79,28 +80,45 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(PdfArgs a) {
         }
         wave_lds_sync();
         // ---- invert the CDF ----
-        float ssum = 0.f;
-        for (int k = lane; k < a.ns_pow2; k += 64) {
-            float smp = __builtin_inff();  // padding of the sort network
-            if (k < ns) {
-                const float u = a.det ? ((ns > 1) ? (float)k / (float)(ns - 1) : 0.f)
-                                      : a.u[ray * ns + k];
-                int lo = 0, hi = nb;  // first index with cdf[idx] > u
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
-                }
-                const int below = max(0, lo - 1), above = min(nb - 1, lo);
-                const float c0 = cdf[below], c1 = cdf[above];
-                float denom = c1 - c0;
-                if (denom < 1e-5f) denom = 1.0f;
-                const float t = (u - c0) / denom;
-                const float b0 = bins[below], b1 = bins[above];
-                smp = b0 + t * (b1 - b0);
-                if (a.samples) a.samples[ray * ns + k] = smp;
-                ssum += smp;
-            }
+        // searchsorted(side='right') as a fixed number of halving steps (no divergence; the
+        // lane's two samples of a round search side by side, which hides half the LDS latency)
+        int top = 1;
+        while (2 * top <= nb) top *= 2;
+        auto draw = [&](int k) { return a.det ? ((ns > 1) ? (float)k / (float)(ns - 1) : 0.f) : a.u[ray * ns + k]; };
+        auto finish = [&](int k, float u, int lo) {  // lo = first index with cdf[idx] > u
+            const int below = max(0, lo - 1), above = min(nb - 1, lo);
+            const float c0 = cdf[below], c1 = cdf[above];
+            float denom = c1 - c0;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (u - c0) / denom;
+            const float b0 = bins[below], b1 = bins[above];
+            const float smp = b0 + t * (b1 - b0);
+            if (a.samples) a.samples[ray * ns + k] = smp;
             sB[k] = smp;
+            if (MERGE && a.det) {
+                // Deterministic uniforms ascend, so the samples do and sample k's slot is k + the
+                // number of coarse depths <= it.  It lies in [z_mid[below], z_mid[above]], so that
+                // number is below + 1 plus the few depths just above that it still reaches.
+                int c = below + 1;
+                while (c < Sc && sA[c] <= smp) ++c;
+                sOut[k + c] = smp;
+            }
+            return smp;
+        };
+        float ssum = 0.f;
+        for (int k0 = lane; k0 < a.ns_pow2; k0 += 128) {
+            const int k1 = k0 + 64;
+            const bool v0 = k0 < ns, v1 = k1 < ns;
+            const float u0 = v0 ? draw(k0) : 0.f, u1 = v1 ? draw(k1) : 0.f;
+            int lo0 = 0, lo1 = 0;
+            for (int step = top; step > 0; step >>= 1) {
+                const int m0 = lo0 + step, m1 = lo1 + step;
+                const float q0 = cdf[min(m0, nb) - 1], q1 = cdf[min(m1, nb) - 1];
+                if (m0 <= nb && q0 <= u0) lo0 = m0;
+                if (m1 <= nb && q1 <= u1) lo1 = m1;
+            }
+            if (v0) ssum += finish(k0, u0, lo0); else sB[k0] = __builtin_inff();  // padding of the sort network
+            if (k1 < a.ns_pow2) { if (v1) ssum += finish(k1, u1, lo1); else sB[k1] = __builtin_inff(); }
         }
         if (a.z_std) {
             const float mean = wave_sum(ssum) / (float)ns;
@@ -131,23 +149,28 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(PdfArgs a) {
                 }
             }
             // rank merge: ties put the coarse depth first
+            int tops = 1, topc = 1;
+            while (2 * tops <= ns) tops *= 2;
+            while (2 * topc <= Sc) topc *= 2;
             for (int i = lane; i < Sc; i += 64) {
                 const float v = sA[i];
-                int lo = 0, hi = ns;  // count of samples < v
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sB[mid] < v) lo = mid + 1; else hi = mid;
+                int lo = 0;  // count of samples < v
+                for (int step = tops; step > 0; step >>= 1) {
+                    const int m = lo + step;
+                    if (m <= ns && sB[min(m, ns) - 1] < v) lo = m;
                 }
                 sOut[i + lo] = v;
             }
-            for (int j = lane; j < ns; j += 64) {
-                const float v = sB[j];
-                int lo = 0, hi = Sc;  // count of coarse depths <= v
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sA[mid] <= v) lo = mid + 1; else hi = mid;
+            if (!a.det) {
+                for (int j = lane; j < ns; j += 64) {
+                    const float v = sB[j];
+                    int lo = 0;  // count of coarse depths <= v
+                    for (int step = topc; step > 0; step >>= 1) {
+                        const int m = lo + step;
+                        if (m <= Sc && sA[min(m, Sc) - 1] <= v) lo = m;
+                    }
+                    sOut[j + lo] = v;
                 }
-                sOut[j + lo] = v;
             }
             wave_lds_sync();
             float* zo = a.z_out + ray * (int64_t)(Sc + ns);
