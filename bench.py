@@ -10,7 +10,9 @@ GPU that is resident in HBM before the clock starts.  With N > 1 every rank rend
 (rays are independent: weak scaling, no collective on the data path) and the ranks all-gather the
 rendered maps (rgb, disp, acc: 20 B/ray) at the end of the step, as a sharded image render would.
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (the fused MLP) from HIP events
-recorded around every one of its launches inside the timed steps; `cpu_baseline` times the
+recorded around every one of its launches inside the timed steps; `hbm_kernels` does the same for
+the bandwidth-bound compositing and resampling launches (algorithmic bytes / event time against
+the 8 TB/s HBM peak); `cpu_baseline` times the
 unfused torch-CPU restatement of the reference's TF op graph (oracle/torch_restatement.py) on a
 bounded sample of the same workload on this host's cores.
 """
@@ -28,6 +30,11 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT = 2 * 593408          # one network, use_viewdirs (run_nerf_helpers.py:95-112)
 MFMA_PEAK_TFLOPS = 2500.0            # dense fp16/bf16 MFMA, MI355X
+HBM_PEAK_GBS = 8000.0                # HBM3E, MI355X
+# bytes one optimisation step moves per query point by construction: saved fp16 activations and
+# ReLU masks written (167 KiB per 32 points), fp16 layer gradients written (154 KiB), masks read
+# by the chain (9 KiB), every saved block read once for the weight gradients (318 KiB)
+TRAIN_BYTES_PER_POINT = (167 + 154 + 9 + 318) * 1024 / 32
 N_RAYS = 1024 * 1024
 N_SAMPLES, N_IMPORTANCE = 64, 128
 
@@ -102,11 +109,14 @@ def train_leg(a, kw_train, models, dev, rank, world, fence):
         dt = float(t.item())
     assert np.isfinite(float(loss)), "training produced a non-finite loss"
     rays_per_s = world * a.n_rand * a.train_steps / dt
-    flop_per_ray = 3 * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_PER_POINT  # fwd + dX + dW
+    points_per_ray = N_SAMPLES + N_SAMPLES + N_IMPORTANCE
+    flop_per_ray = 3 * points_per_ray * FLOP_PER_POINT  # fwd + dX + dW
+    gbs = rays_per_s * points_per_ray * TRAIN_BYTES_PER_POINT / 1e9
     return {"rays_per_s": round(rays_per_s, 1), "ms_per_step": round(dt / a.train_steps * 1e3, 3),
             "steps": a.train_steps, "n_rand_per_gpu": a.n_rand, "scaling": "weak",
             "algorithmic_tflops": round(rays_per_s * flop_per_ray / 1e12, 2),
             "frac_of_mfma_peak": round(rays_per_s * flop_per_ray / 1e12 / MFMA_PEAK_TFLOPS / world, 4),
+            "bound": "hbm", "hbm_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS / world, 4),
             "final_loss": round(float(loss), 6)}
 
 
@@ -160,12 +170,14 @@ def main():
         step()
     fence()
     ops.MLP_TIMING = []
+    ops.HBM_TIMING = {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
         rgb = step()
     fence()
     dt = time.perf_counter() - t0
     timing, ops.MLP_TIMING = ops.MLP_TIMING, None
+    hbm_timing, ops.HBM_TIMING = ops.HBM_TIMING, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,6 +192,14 @@ def main():
     mlp_points = sum(p for _, _, p in timing)
     achieved = mlp_points * FLOP_PER_POINT / (mlp_ms * 1e-3) / 1e12
     rays_per_s = world * a.rays * a.steps / dt
+
+    hbm_kernels = []
+    for name, ev in sorted(hbm_timing.items()):
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
+        gbs = sum(b for _, _, b in ev) / (ms * 1e-3) / 1e9
+        hbm_kernels.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": len(ev),
+                            "avg_launch_ms": round(ms / len(ev), 4), "share_of_step": round(ms * 1e-3 / dt, 5)})
 
     if rank == 0:
         cpu = None
@@ -204,6 +224,7 @@ def main():
                          "avg_launch_ms": round(mlp_ms / max(1, len(timing)), 4),
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": mlp_points // max(1, len(timing)),
                          "mlp_share_of_step": round(mlp_ms * 1e-3 / dt, 4)},
+            "hbm_kernels": hbm_kernels,
             "cpu_baseline": cpu,
             "train": train,
         }

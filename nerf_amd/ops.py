@@ -138,6 +138,21 @@ def sample_z(rays, S, lindisp=False, perturb_u=None):
 MLP_TIMING = None
 
 
+# When a dict, the compositing and resampling launches append (start_event, end_event,
+# algorithmic bytes) under their kernel's name -- bench.py's HBM-bound kernels.
+HBM_TIMING = None
+
+
+def _timed_hbm(name, nbytes, launch):
+    if HBM_TIMING is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    HBM_TIMING.setdefault(name, []).append((e0, e1, nbytes))
+
+
 def _timed_mlp(points, launch):
     if MLP_TIMING is None:
         return launch()
@@ -198,11 +213,13 @@ def composite_fwd(raw, z, rays_d, d_stride, white_bkgd=False, noise=None, noise_
     depth = torch.empty((n,), dtype=torch.float32, device=dev)
     weights = torch.empty((n, S), dtype=torch.float32, device=dev) if want_weights else None
     with torch.cuda.device(dev):
-        nv.check(nv.lib().nerf_composite_fwd(nv.ptr(raw), nv.ptr(z), ctypes.c_void_p(rays_d.data_ptr()),
-                                             int(d_stride), n, S, int(bool(white_bkgd)),
-                                             nv.ptr(noise), float(noise_std), nv.ptr(rgb),
-                                             nv.ptr(disp), nv.ptr(acc), nv.ptr(depth),
-                                             nv.ptr(weights), nv.stream()), "nerf_composite_fwd")
+        # algorithmic bytes: raw 16 S + z 4 S + direction 12 read, weights 4 S + maps 24 written
+        _timed_hbm(f"composite_fwd S={S}", n * (24 * S + 36), lambda: nv.check(
+            nv.lib().nerf_composite_fwd(nv.ptr(raw), nv.ptr(z), ctypes.c_void_p(rays_d.data_ptr()),
+                                        int(d_stride), n, S, int(bool(white_bkgd)),
+                                        nv.ptr(noise), float(noise_std), nv.ptr(rgb),
+                                        nv.ptr(disp), nv.ptr(acc), nv.ptr(depth),
+                                        nv.ptr(weights), nv.stream()), "nerf_composite_fwd"))
     return rgb, disp, acc, weights, depth
 
 
@@ -250,10 +267,12 @@ def resample_merge(z_vals, weights, N_importance, det=True, u=None, want_samples
     z_samples = torch.empty((n, N_importance), dtype=torch.float32, device=dev) if want_samples else None
     z_std = torch.empty((n,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        nv.check(nv.lib().nerf_resample_merge(nv.ptr(z_vals), nv.ptr(weights), n, Sc,
-                                              int(N_importance), int(bool(det)), nv.ptr(u),
-                                              nv.ptr(z_out), nv.ptr(z_samples), nv.ptr(z_std),
-                                              nv.stream()), "nerf_resample_merge")
+        # algorithmic bytes: z and weights read (8 Sc), merged depths written (4 (Sc + Si))
+        _timed_hbm(f"resample_merge {Sc}+{N_importance}", n * (8 * Sc + 4 * (Sc + N_importance)), lambda: nv.check(
+            nv.lib().nerf_resample_merge(nv.ptr(z_vals), nv.ptr(weights), n, Sc,
+                                         int(N_importance), int(bool(det)), nv.ptr(u),
+                                         nv.ptr(z_out), nv.ptr(z_samples), nv.ptr(z_std),
+                                         nv.stream()), "nerf_resample_merge"))
     return z_out, z_samples, z_std
 
 
