@@ -469,9 +469,7 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
                 asm volatile("s_barrier" ::: "memory");
                 // the buffer read in the previous iteration is free again (every wave passed the barrier)
                 constexpr int nbuf = (buf + kAhead) % kDwStages;
-#ifndef EXP_DW_NOLOAD
                 if (it + kAhead < nstage) stage_in(it + kAhead, nbuf);
-#endif
                 if constexpr (ROW) {
                     if (wave < NX) {
 #pragma unroll
