@@ -99,8 +99,9 @@ struct WNoPrev {
 // Tile number TL inside its layer (of NT): tiles 2s, 2s+1 fill the low / high half of fragment s.
 // STORE: a finished fragment s of point tile pt is saved as block ABLK + 2s + pt, and for
 // MBLK >= 0 the layer's ReLU mask bits are collected in mk[] and saved as block MBLK after the
-// last tile: dword 2 pt + (TL >> 3) of the lane, bit 4 (TL & 7) + r = register r of tile TL > 0,
-// i.e. unit 16 TL + 4 (lane >> 4) + r of point 16 pt + (lane & 15).
+// last tile.  With i = 2 TL + (r >> 1) numbering the register pairs of the layer: dword
+// 2 pt + (i >> 4) of the lane, bit (i & 15) + 16 (r & 1) = register r of tile TL > 0, i.e. unit
+// 16 TL + 4 (lane >> 4) + r of point 16 pt + (lane & 15).
 template <bool RELU, int TL, bool STORE = false, int ABLK = 0, int MBLK = -1, int NT = 0>
 struct WToFrag {
     static constexpr bool kActive = true;
@@ -119,10 +120,13 @@ struct WToFrag {
         f[e] = p[0], f[e + 1] = p[1];
         if constexpr (STORE) {
             if constexpr (MBLK >= 0) {
-                const unsigned pw = __builtin_bit_cast(unsigned, p);
-                const unsigned bits = ((pw & 0xFFFFu) ? 1u : 0u) | ((pw >> 16) ? 2u : 0u);
-                constexpr int sh = 4 * (TL & 7) + 2 * q, w = 2 * pt + (TL >> 3);
-                if constexpr (sh == 0) mk[w] = bits; else mk[w] |= bits << sh;
+                // both halves clamped to {0, 1} by one packed min, shifted into place by one
+                // shift-or: two instructions per pair of units
+                // (inline asm: the compiler expands a packed u16 min into five instructions)
+                unsigned flags;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(flags) : "v"(__builtin_bit_cast(unsigned, p)), "s"(0x00010001u));
+                constexpr int si = 2 * TL + q, sh = si & 15, w = 2 * pt + (si >> 4);
+                if constexpr (sh == 0) mk[w] = flags; else mk[w] |= flags << sh;
             }
             if constexpr ((TL & 1) == 1 && q == 1) sink.template put<ABLK + 2 * (TL >> 1) + pt>(f);
             if constexpr (MBLK >= 0 && TL == NT - 1 && S == 3)

@@ -36,8 +36,9 @@ constexpr int A_BOTT = 132;  // 16 blocks: bottleneck (linear)
 constexpr int A_V = 148;     //  8 blocks: view layer output (after ReLU)
 constexpr int A_VPE = 156;   //  2 blocks: view-direction encoding (32 slots)
 constexpr int A_MASK = 158;  //  1 block per layer output h0..h7 and one for v (A_MASK + 8): ReLU masks, one
-                             //  bit per unit: lane = point + 16 g holds dwords [point tile][2]; bit
-                             //  4 (t & 7) + r of dword t >> 3 = unit 16 t + 4 g + r is > 0
+                             //  bit per unit: lane = point + 16 g holds dwords [point tile][2]; with
+                             //  i = 2 t + (r >> 1), bit (i & 15) + 16 (r & 1) of dword i >> 4 = unit
+                             //  16 t + 4 g + r is > 0
 constexpr int kActBlocks = 167;
 
 // Gradients come from the 32x32x16 chain: a block is k-step k (16 features) of the 32 points,

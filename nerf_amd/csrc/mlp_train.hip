@@ -84,7 +84,8 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 // VmQueue like the weight stream's loads (a load the compiler knows about would make it wait for
 // vmcnt(0), i.e. for the whole stream and every pending store, before the first use).
 // The forward (16x16x32 tiles: lane = point & 15 + 16 g, g = 0..3) saved, per lane, dwords
-// [point tile][2]: bit 4 (t & 7) + r of dword t >> 3 = unit 16 t + 4 g + r.  A lane of this kernel
+// [point tile][2]: with i = 2 t + (r >> 1), bit (i & 15) + 16 (r & 1) of dword i >> 4 = unit
+// 16 t + 4 g + r.  A lane of this kernel
 // (32x32x16 tiles: point = lane & 31, half h) holds units with (unit >> 2) & 1 == h, i.e. the
 // pieces g = h and g = h + 2 of its point: two 8-byte loads, v[0:1] and v[2:3].
 struct MaskLoad {
@@ -151,10 +152,12 @@ struct CToFrags {
         half2v p = __builtin_convertvector(x, half2v);
         if constexpr (MASKED) {
             // registers 2S, 2S+1 of 32-unit tile TL = units 16 t + 4 g + r with t = 2 TL + (S >> 2),
-            // g = h + 2 ((S >> 1) & 1), r = 2 S & 3 (+1): see MaskLoad
-            constexpr int t = 2 * TL + (S >> 2), piece = (S >> 1) & 1, sh = 4 * (t & 7) + ((2 * S) & 3);
-            const unsigned w = mk[2 * piece + (t >> 3)] >> sh;
-            const unsigned keep = ((w & 1u) ? 0x0000FFFFu : 0u) | ((w & 2u) ? 0xFFFF0000u : 0u);
+            // g = h + 2 ((S >> 1) & 1), r = 2 (S & 1) (+1): pair i = 2 t + (S & 1) of the forward's
+            // numbering, flags at bits (i & 15) and (i & 15) + 16 of dword i >> 4 (see MaskLoad)
+            constexpr int i = 2 * (2 * TL + (S >> 2)) + (S & 1), piece = (S >> 1) & 1;
+            const unsigned m = (mk[2 * piece + (i >> 4)] >> (i & 15)) & 0x00010001u;
+            unsigned keep;  // 0 / 0xFFFF per half (inline asm: the compiler scalarises packed u16 arithmetic)
+            asm("v_pk_sub_u16 %0, 0, %1" : "=v"(keep) : "v"(m));
             p = __builtin_bit_cast(half2v, __builtin_bit_cast(unsigned, p) & keep);
         }
         half8& f = dst[2 * TL + (S >> 2)];

@@ -85,7 +85,8 @@ def test_forward_train_matches_inference_and_saves_activations(gpu):
             for j in range(8):
                 f = 32 * s_ + 16 * (j >> 2) + 4 * g + (j & 3)
                 assert abs(h7[b, lane, j] - hcur[c, f]) < 2e-3 * max(1., abs(hcur[c, f])), (b, lane, j)
-    # the mask block of h7: bit 4 (t & 7) + r of dword [pt][t >> 3] of lane (point, g) = unit 16 t + 4 g + r
+    # the mask block of h7: with i = 2 t + (r >> 1), bit (i & 15) + 16 (r & 1) of dword [pt][i >> 4] of
+    # lane (point, g) = unit 16 t + 4 g + r
     mk = blk[158 + 7].contiguous().view(torch.int32).view(64, 4).cpu().numpy().astype(np.uint32)
     for lane in range(64):
         g = lane >> 4
@@ -93,7 +94,8 @@ def test_forward_train_matches_inference_and_saves_activations(gpu):
             c = 16 * pt + (lane & 15)
             for t in range(16):
                 for r_ in range(4):
-                    bit = (int(mk[lane, 2 * pt + (t >> 3)]) >> (4 * (t & 7) + r_)) & 1
+                    i_ = 2 * t + (r_ >> 1)
+                    bit = (int(mk[lane, 2 * pt + (i_ >> 4)]) >> ((i_ & 15) + 16 * (r_ & 1))) & 1
                     f = 16 * t + 4 * g + r_
                     val = h7[2 * (f >> 5) + pt, (lane & 15) + 16 * ((f >> 2) & 3), 4 * ((f & 31) >> 4) + (f & 3)]
                     assert bit == int(val != 0), (lane, pt, t, r_)
