@@ -153,23 +153,35 @@ struct Stream {
     static_assert(DEPTH <= RING - 2 && kPrefetch <= 8, "ring slack");
     static constexpr int kRingBytes = RING * kChunkBytes;
     VmQueue& vm;
-    const char* gsrc;   // this lane's source address inside chunk 0
+    const char* gsrc;   // this wave's 2 KiB share of chunk 0 (wave-uniform: loads take it as a scalar base)
     char* lds;          // ring base
     int wave_off;       // this wave's 2 KiB share of a chunk
     int lane_off;       // lane * 16
+    // This lane's read addresses of ring bytes 0 and 65536, kept as two opaque registers so that
+    // every fragment read is base + 16-bit immediate (a ds_read offset ends at 65535; left to
+    // itself the compiler forms the upper addresses with one vector instruction per read).
+    const char* rd_lo;
+    const char* rd_hi;
     int mark[RING];     // vm.issued right after each resident chunk's loads
     half8 a[kPrefetch];
 
     DEV Stream(VmQueue& q, const char* packed, char* lds_base, int wave, int lane)
-        : vm(q), gsrc(packed + wave * (2 * kFragBytes) + lane * 16), lds(lds_base),
-          wave_off(wave * (2 * kFragBytes)), lane_off(lane * 16) {}
+        : vm(q), gsrc(packed + wave * (2 * kFragBytes)), lds(lds_base),
+          wave_off(wave * (2 * kFragBytes)), lane_off(lane * 16) {
+        unsigned lo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds_base + lane * 16);
+        unsigned hi = lo + 65536u;
+        asm volatile("" : "+v"(lo));
+        asm volatile("" : "+v"(hi));
+        rd_lo = (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)lo;
+        rd_hi = (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)hi;
+    }
 
     template <int C>
     DEV void issue() {
         const char* g = gsrc + (size_t)C * kChunkBytes;
         char* l = lds + (C % RING) * kChunkBytes + wave_off;
-        glds16_untracked(g, l);
-        glds16_untracked(g + kFragBytes, l + kFragBytes);
+        glds16_untracked_sbase(g, (unsigned)lane_off, l);
+        glds16_untracked_sbase(g + kFragBytes, (unsigned)lane_off, l + kFragBytes);
         vm.issued += 2;
         mark[C % RING] = vm.issued;
     }
@@ -187,8 +199,9 @@ struct Stream {
     template <int F>
     DEV half8 read() const {
         constexpr int C = F / kFragsPerChunk;
-        const char* p = lds + (C % RING) * kChunkBytes + (F % kFragsPerChunk) * kFragBytes + lane_off;
-        return *(const half8*)p;
+        constexpr int off = (C % RING) * kChunkBytes + (F % kFragsPerChunk) * kFragBytes;
+        if constexpr (off < 65536) return *(const half8*)(rd_lo + off);
+        else return *(const half8*)(rd_hi + (off - 65536));
     }
 
     // Issues the first DEPTH chunks (call early, before any other work).

@@ -309,7 +309,11 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     auto from_b = [&](auto pt, auto kc) { return fb[decltype(pt)::value * kS + decltype(kc)::value]; };
     static_assert(WToFrag<true, 0>::kStride == kS, "fragment set stride");
 
-    WidePipe pp{st, lds + kWRingBytes + g * 16, {}};
+    // the bias table's address for this lane group, opaque to the compiler so that every bias
+    // read is this register + an immediate (the table lies beyond a ds_read's 16-bit offset)
+    unsigned bias_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + kWRingBytes + g * 16);
+    asm volatile("" : "+v"(bias_addr));
+    WidePipe pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}};
     st.start();
     {
         const f32x4 b = *(const f32x4*)(pp.bias);
