@@ -151,3 +151,41 @@ def test_render_full_size_is_chunk_invariant(gpu):
     target = (ref + torch.randn(ref.shape, generator=g, device=gpu, dtype=torch.float64) * 0.05).clamp(0, 1)
     psnr = lambda x: float(-10. * torch.log10(torch.mean((x - target) ** 2)))
     assert abs(psnr(rgb[sl].double()) - psnr(ref)) <= 0.05
+
+
+def test_llff_view_256_plus_128_samples(gpu):
+    """The forward-facing stress configuration at full size: a 1008 x 756 view through get_rays ->
+    viewdirs -> ndc_rays (near plane 1) -> near 0 / far 1 with 256 coarse + 128 fine samples
+    (long per-ray scans: 4 and 6 chunks of 64).  Chunk invariance over the whole view and the
+    float64 restatement of the whole path on two rows of pixels."""
+    from nerf_amd import ops
+    from nerf_amd.run_nerf import create_nerf, render
+    H, W, focal = 756, 1008, 815.0
+    args = default_args(white_bkgd=False, dataset_type='llff', N_samples=256, N_importance=128)
+    kw_train, kw_test, _, _, models = create_nerf(args)
+    rng = np.random.default_rng(31)
+    models['model'].set_weights(trained_like_weights(rng))
+    models['model_fine'].set_weights(trained_like_weights(rng))
+    c2w = np.concatenate([np.eye(3), np.array([[0.05], [0.02], [0.1]])], 1).astype(np.float32)
+    a = render(H, W, focal, chunk=1024 * 64, c2w=torch.as_tensor(c2w), near=0., far=1., **kw_test)
+    b = render(H, W, focal, chunk=1024 * 32, c2w=torch.as_tensor(c2w), near=0., far=1., **kw_test)
+    rgb, disp, acc = a[:3]
+    assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and a[3]['rgb0'].shape == (H, W, 3)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert bool(torch.isfinite(rgb).all()) and float(acc.max()) <= 1. + FP32_TOL
+    # rows 300 and 301 (2016 rays) against the restatement, fed the same ray batch
+    o, d = ops.get_rays(H, W, focal, torch.as_tensor(c2w))
+    rays = ops.build_ray_batch(o, d, d, True, H, W, focal, 0., 1.)
+    sl = slice(300 * W, 302 * W)
+    wc = [torch.as_tensor(w, device=gpu).double() for w in models['model'].get_weights()]
+    wf = [torch.as_tensor(w, device=gpu).double() for w in models['model_fine'].get_weights()]
+    ref = trs.render_flat(rays[sl].double(), wc, wf, N_samples=256, N_importance=128, white_bkgd=False)
+    got = rgb.reshape(-1, 3)[sl].double()
+    err = (got - ref['rgb_map']).abs()
+    assert float(torch.quantile(err.flatten(), 0.99)) < RGB_TOL, float(torch.quantile(err.flatten(), 0.99))
+    g = torch.Generator(device=gpu)
+    g.manual_seed(1)
+    target = (ref['rgb_map'] + torch.randn(ref['rgb_map'].shape, generator=g, device=gpu, dtype=torch.float64) * 0.05).clamp(0, 1)
+    psnr = lambda x: float(-10. * torch.log10(torch.mean((x - target) ** 2)))
+    assert abs(psnr(got) - psnr(ref['rgb_map'])) <= 0.05
