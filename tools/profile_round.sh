@@ -5,7 +5,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/r01b
+O=$R/gpurun_out/r01c
 rm -rf $O && mkdir -p $O
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-rays 0 > $O/bench_under_rocprof.json 2> $O/stats.err
 B="python3 $R/bench.py --steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --rays 262144"
