@@ -124,9 +124,8 @@ DEV void glds16_untracked(const void* gsrc, void* lds_dst) {
 // offset: address arithmetic stays on the scalar unit and a lane keeps one register per distinct
 // offset pattern instead of a 64-bit pointer per load.
 template <bool STREAMED = false>
-DEV void glds16_untracked_sbase(const void* base, unsigned lane_off, void* lds_dst) {
-    const unsigned addr = __builtin_amdgcn_readfirstlane(
-        (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
+DEV void glds16_untracked_sbase(const void* base, unsigned lane_off, unsigned lds_addr) {
+    const unsigned addr = __builtin_amdgcn_readfirstlane(lds_addr);
     // `base` must be the same in every lane; say so to the compiler (an "s" operand it believes
     // divergent is silently passed in vector registers)
     const uint64_t b = (uint64_t)(uintptr_t)base;
@@ -148,14 +147,22 @@ DEV void glds16_untracked_sbase(const void* base, unsigned lane_off, void* lds_d
 
 // The weight stream (NCHUNKS chunks of 16 KiB, RING LDS slots, DEPTH chunks in flight) and the
 // register pipeline of A fragments.  Fragments must be taken in stream order, F = 0, 1, 2, ...
-template <int NCHUNKS, int RING, int DEPTH>
+//
+// WRAP: the workgroup consumes the same stream once per tile of its persistent loop, and the
+// first DEPTH chunks of the next pass are requested during the tail of the current one, so that
+// a pass never starts with an empty ring (after the last pass they are loaded for nothing: the
+// kernel drains the queue before it ends).  Ring slots are compile-time (chunk % RING), so
+// NCHUNKS must be a multiple of RING; chunks NLOAD .. NCHUNKS-1 exist only as slot numbers
+// (nothing is loaded for them, nothing reads them).
+template <int NCHUNKS, int RING, int DEPTH, int NLOAD = NCHUNKS, bool WRAP = false>
 struct Stream {
     static_assert(DEPTH <= RING - 2 && kPrefetch <= 8, "ring slack");
+    static_assert(!WRAP || NCHUNKS % RING == 0, "a wrapping stream keeps its slot phase");
+    static_assert(NLOAD <= NCHUNKS && NCHUNKS - NLOAD <= 1, "at most one slot-only chunk");
     static constexpr int kRingBytes = RING * kChunkBytes;
     VmQueue& vm;
     const char* gsrc;   // this wave's 2 KiB share of chunk 0 (wave-uniform: loads take it as a scalar base)
-    char* lds;          // ring base
-    int wave_off;       // this wave's 2 KiB share of a chunk
+    unsigned wr;        // LDS address of this wave's 2 KiB share of ring slot 0 (wave-uniform)
     int lane_off;       // lane * 16
     // This lane's read addresses of ring bytes 0 and 65536, kept as two opaque registers so that
     // every fragment read is base + 16-bit immediate (a ds_read offset ends at 65535; left to
@@ -166,8 +173,10 @@ struct Stream {
     half8 a[kPrefetch];
 
     DEV Stream(VmQueue& q, const char* packed, char* lds_base, int wave, int lane)
-        : vm(q), gsrc(packed + wave * (2 * kFragBytes)), lds(lds_base),
-          wave_off(wave * (2 * kFragBytes)), lane_off(lane * 16) {
+        : vm(q), gsrc(packed + wave * (2 * kFragBytes)),
+          wr(__builtin_amdgcn_readfirstlane(
+              (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds_base + wave * (2 * kFragBytes)))),
+          lane_off(lane * 16) {
         unsigned lo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds_base + lane * 16);
         unsigned hi = lo + 65536u;
         asm volatile("" : "+v"(lo));
@@ -178,11 +187,13 @@ struct Stream {
 
     template <int C>
     DEV void issue() {
-        const char* g = gsrc + (size_t)C * kChunkBytes;
-        char* l = lds + (C % RING) * kChunkBytes + wave_off;
-        glds16_untracked_sbase(g, (unsigned)lane_off, l);
-        glds16_untracked_sbase(g + kFragBytes, (unsigned)lane_off, l + kFragBytes);
-        vm.issued += 2;
+        if constexpr (C < NLOAD) {
+            const char* g = gsrc + (size_t)C * kChunkBytes;
+            const unsigned l = wr + (C % RING) * kChunkBytes;
+            glds16_untracked_sbase(g, (unsigned)lane_off, l);
+            glds16_untracked_sbase(g + kFragBytes, (unsigned)lane_off, l + kFragBytes);
+            vm.issued += 2;
+        }
         mark[C % RING] = vm.issued;
     }
 
@@ -193,7 +204,33 @@ struct Stream {
         vm.wait_until(mark[C % RING]);
         asm volatile("s_barrier" ::: "memory");
         if constexpr (C + DEPTH < NCHUNKS) issue<C + DEPTH>();
+        else if constexpr (WRAP) issue<C + DEPTH - NCHUNKS>();
         __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // WRAP, after the last fragment of a pass: the barrier of the slot-only last chunk (every wave
+    // is past the pass, so the slot two chunks back is free), then the next pass's chunk that
+    // belongs there.  The next pass begins with start(), not prologue().
+    DEV void finish_pass() {
+        static_assert(!WRAP || NLOAD == NCHUNKS - 1, "finish_pass stands in for the sync of the slot-only chunk");
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        issue<DEPTH - 1>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // WRAP, at the top of every pass (the first one included, after prologue()): restarts the
+    // queue bookkeeping from constants, so that every wait of a pass is an immediate.  Chunks
+    // 0 .. DEPTH-1 are in flight, issued in that order; whatever else was issued between them
+    // only makes the true distance of a chunk from the queue's tail larger than the 2 loads per
+    // younger chunk assumed here, so the waits are at worst stricter than needed.
+    DEV void rebase() {
+        constexpr int kBase = 1 << 20;
+        static_for<0, DEPTH>([&](auto c) { mark[decltype(c)::value % RING] = kBase - 2 * (DEPTH - 1 - decltype(c)::value); });
+        vm.issued = kBase;
+        // a new value per pass as far as the compiler can tell: otherwise it computes the 64-bit
+        // source address of every chunk once, outside the loop, and keeps them all in registers
+        asm volatile("" : "+s"(gsrc), "+s"(wr));
     }
 
     template <int F>

@@ -3,7 +3,12 @@
 // resident in registers from the first layer to the last (see mlp_layout_wide.h).
 //
 // Work decomposition.  A workgroup is 8 waves (2 per SIMD); each wave owns 32 query points (two
-// 16-point tiles) for the whole network, so a workgroup covers 256 points.  A layer is computed
+// 16-point tiles) for the whole network, so a workgroup covers 256 points at a time.  Workgroups
+// are persistent (one per CU, tiles of 256 points dealt round-robin): while a tile's last layers
+// run, the weight stream already refills the ring for the next tile and the next tile's rays
+// and depths are fetched, so a CU never waits for a workgroup launch, a cold ring or its inputs
+// (measured before: 3.0 us from workgroup start to the first chunk + 2.2 us between workgroups,
+// of 52.6 us per tile).  A layer is computed
 // one 16-row output tile at a time: one A fragment per k-step feeds two v_mfma_f32_16x16x32_f16
 // (one per point tile), 2 x 4 fp32 accumulator registers seeded with the biases.  A finished tile
 // is converted (fp16 rounding, then a packed ReLU) in four slices placed between the MFMAs of the
@@ -35,9 +40,13 @@ struct FwdWideArgs {
     int S;                  // points per ray
 };
 
-constexpr int kWRing = 8;   // LDS ring slots (16 KiB each)
-constexpr int kWDepth = 6;  // chunks in flight ahead of the chunk being synchronised
-using WideStream = Stream<lw::kChunks, kWRing, kWDepth>;
+// The ring: 5 slots of 16 KiB, 3 chunks in flight (measured equal to 8 / 6).  The 74 chunks of a
+// network count as 75 ring positions, a multiple of the slot count, so that a workgroup can run
+// the stream again for its next 256 points with the same compile-time slot of every chunk.
+constexpr int kWRing = 5;
+constexpr int kWDepth = 3;
+constexpr int kWRingChunks = lw::kChunks + 1;
+using WideStream = Stream<kWRingChunks, kWRing, kWDepth, lw::kChunks, true>;
 constexpr int kWRingBytes = WideStream::kRingBytes;
 
 DEV f32x4 mfma_wide(half8 a, half8 b, f32x4 c) {
@@ -243,12 +252,94 @@ DEV void encode_view(const float (&x)[3], int g, half8 (&out)[1]) {
     pack_slots<8>(v, out);
 }
 
+// The words a lane reads for one query point.  MODE 0 (rays + depths): q4 = o.xyz, d.x; q2a = d.yz;
+// q2b = viewdir.xy; s1 = viewdir.z; s2 = depth.  MODE 1 (explicit points): q2a = p.xy; s1 = p.z;
+// q2b = viewdir.xy; s2 = viewdir.z.
+struct PointWords {
+    f32x4 q4;
+    f32x2 q2a, q2b;
+    float s1, s2;
+};
+
+template <int MODE>
+DEV void point_addresses(const FwdWideArgs& a, int64_t tile, int wave, int lane, int pt,
+                         const float*& pa, const float*& pb, const float*& pz) {
+    const int64_t p = tile * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (lane & 15);
+    const int64_t pc = p < a.M ? p : a.M - 1;
+    const int64_t ray = pc / a.S;
+    if (MODE == 0) pa = a.rays + ray * a.width, pb = pa + 8, pz = a.z + pc;
+    else pa = a.pts + pc * 3, pb = a.viewdirs + ray * 3, pz = nullptr;
+}
+
+// Plain loads (first tile of a workgroup: nothing else is in flight yet).
+template <int MODE>
+DEV PointWords load_point(const FwdWideArgs& a, int64_t tile, int wave, int lane, int pt) {
+    const float *pa, *pb, *pz;
+    point_addresses<MODE>(a, tile, wave, lane, pt, pa, pb, pz);
+    PointWords w{};
+    if (MODE == 0) {
+        w.q4 = f32x4{pa[0], pa[1], pa[2], pa[3]}, w.q2a = f32x2{pa[4], pa[5]};
+        w.q2b = f32x2{pb[0], pb[1]}, w.s1 = pb[2], w.s2 = *pz;
+    } else {
+        w.q2a = f32x2{pa[0], pa[1]}, w.s1 = pa[2], w.q2b = f32x2{pb[0], pb[1]}, w.s2 = pb[2];
+    }
+    return w;
+}
+
+// The same loads issued from inline asm and counted in the wave's vector-memory queue, for the
+// NEXT tile while the current one computes (a load the compiler knows about would be waited for
+// with vmcnt(0), draining the weight stream).
+struct PointFetch {
+    PointWords w;
+    int mark;
+    template <int MODE>
+    DEV void issue(VmQueue& vm, const FwdWideArgs& a, int64_t tile, int wave, int lane, int pt) {
+        const float *pa, *pb, *pz;
+        point_addresses<MODE>(a, tile, wave, lane, pt, pa, pb, pz);
+        if (MODE == 0) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.q4) : "v"(pa) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=v"(w.q2a) : "v"(pa) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(w.q2b) : "v"(pb) : "memory");
+            asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(w.s1) : "v"(pb) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(w.s2) : "v"(pz) : "memory");
+            vm.issued += 5;
+        } else {
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(w.q2a) : "v"(pa) : "memory");
+            asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(w.s1) : "v"(pa) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(w.q2b) : "v"(pb) : "memory");
+            asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(w.s2) : "v"(pb) : "memory");
+            vm.issued += 4;
+        }
+        mark = vm.issued;
+    }
+    DEV PointWords get(const VmQueue& vm) {
+        vm.wait_until(mark);
+        asm volatile("" : "+v"(w.q4), "+v"(w.q2a), "+v"(w.q2b), "+v"(w.s1), "+v"(w.s2));
+        return w;
+    }
+};
+
+template <int MODE>
+DEV void point_xyz(const PointWords& w, float (&x)[3], float (&vd)[3]) {
+    if (MODE == 0) {
+        const float zz = w.s2;
+        x[0] = w.q4[0] + w.q4[3] * zz;  // pts = rays_o + rays_d * z
+        x[1] = w.q4[1] + w.q2a[0] * zz;
+        x[2] = w.q4[2] + w.q2a[1] * zz;
+        vd[0] = w.q2b[0], vd[1] = w.q2b[1], vd[2] = w.s1;
+    } else {
+        x[0] = w.q2a[0], x[1] = w.q2a[1], x[2] = w.s1;
+        vd[0] = w.q2b[0], vd[1] = w.q2b[1], vd[2] = w.s2;
+    }
+}
+
 template <int MODE, bool STORE>
 __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[kWRingBytes + lw::kBiasBytes];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
+    const int64_t ntiles = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
 
     VmQueue vm;
     WideStream st(vm, a.packed, lds, wave, lane);
@@ -258,52 +349,8 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
                          lds + kWRingBytes + blk * kFragBytes);
     st.prologue();
 
-    // ---- this lane's two query points (one per point tile) and their view directions ----
     constexpr int kS = 8;  // fragments (k-steps of 32 features) per point tile in a set
     half8 fa[2 * kS], fb[2 * kS], pe[2][2], vpe[2][1];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (lane & 15);
-        const int64_t pc = p < a.M ? p : a.M - 1;
-        const int64_t ray = pc / a.S;
-        float x[3], vd[3];
-        if (MODE == 0) {
-            const float* r = a.rays + ray * a.width;
-            const float zz = a.z[pc];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                x[c] = r[c] + r[3 + c] * zz;  // pts = rays_o + rays_d * z
-                vd[c] = r[8 + c];
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                x[c] = a.pts[pc * 3 + c];
-                vd[c] = a.viewdirs[ray * 3 + c];
-            }
-        }
-        encode_point(x, g, pe[pt]);
-        encode_view(vd, g, vpe[pt]);
-    }
-
-    WSink sink{nullptr, &vm};
-    const char* act_tile = nullptr;  // this wave's tile of saved activations (wave-uniform)
-    if constexpr (STORE) {
-        const int64_t wave_tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-        act_tile = a.act + (size_t)wave_tile * kActBlocks * kFragBytes;
-        sink.base = a.act + (size_t)wave_tile * kActBlocks * kFragBytes + lane * 16;
-        static_for<0, 2>([&](auto sc) {
-            constexpr int k = decltype(sc)::value;
-            sink.template put<A_PE + 2 * k>(pe[0][k]);
-            sink.template put<A_PE + 2 * k + 1>(pe[1][k]);
-        });
-        sink.template put<A_VPE>(vpe[0][0]);
-        sink.template put<A_VPE + 1>(vpe[1][0]);
-    }
-    const int enc_saved = vm.issued;  // the saved encodings are in memory once the queue is past this mark
-    FragLoad lpe[4], lvpe[2];
-    unsigned mk[4] = {0u, 0u, 0u, 0u};
-
     auto from_pe = [&](auto pt, auto kc) { return pe[decltype(pt)::value][decltype(kc)::value]; };
     auto from_a = [&](auto pt, auto kc) { return fa[decltype(pt)::value * kS + decltype(kc)::value]; };
     auto from_b = [&](auto pt, auto kc) { return fb[decltype(pt)::value * kS + decltype(kc)::value]; };
@@ -314,60 +361,110 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     unsigned bias_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + kWRingBytes + g * 16);
     asm volatile("" : "+v"(bias_addr));
     WidePipe pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}};
-    st.start();
-    {
-        const f32x4 b = *(const f32x4*)(pp.bias);
-        pp.acc[0][0] = b, pp.acc[0][1] = b;
-    }
-    auto c0 = wide_layer<lw::F_L0, 16, 2, lw::T_L0, true, STORE, A_H0, A_MASK + 0>(pp, sink, mk, fa, from_pe, WNoPrev{});                     // layer 0
-    auto c1 = wide_layer<lw::F_L1 + 0 * 128, 16, 8, lw::T_L1 + 0, true, STORE, A_H0 + 16, A_MASK + 1>(pp, sink, mk, fb, from_a, c0);        // layers 1..4
-    auto c2 = wide_layer<lw::F_L1 + 1 * 128, 16, 8, lw::T_L1 + 16, true, STORE, A_H0 + 32, A_MASK + 2>(pp, sink, mk, fa, from_b, c1);
-    auto c3 = wide_layer<lw::F_L1 + 2 * 128, 16, 8, lw::T_L1 + 32, true, STORE, A_H0 + 48, A_MASK + 3>(pp, sink, mk, fb, from_a, c2);
-    if constexpr (STORE) {  // the point encoding comes back during layer 4 (blocks A_PE + 2k + pt)
-        vm.wait_until(enc_saved);
-        static_for<0, 4>([&](auto ic) { lpe[decltype(ic)::value].issue(vm, act_tile + (A_PE + decltype(ic)::value) * kFragBytes, lane * 16); });
-    }
-    auto c4 = wide_layer<lw::F_L1 + 3 * 128, 16, 8, lw::T_L1 + 48, true, STORE, A_H0 + 64, A_MASK + 4>(pp, sink, mk, fa, from_b, c3);
-    half8 pe5[2][2];
-    static_for<0, 4>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, k = i >> 1, pt = i & 1;
-        if constexpr (STORE) pe5[pt][k] = lpe[i].get(vm); else pe5[pt][k] = pe[pt][k];
-    });
-    auto c5 = wide_layer<lw::F_L5, 16, 10, lw::T_L5, true, STORE, A_H0 + 80, A_MASK + 5>(pp, sink, mk, fb, [&](auto pt, auto kc) {         // layer 5: [PE ; h]
-        constexpr int k = decltype(kc)::value;
-        if constexpr (k < 2) return pe5[decltype(pt)::value][k]; else return fa[decltype(pt)::value * kS + k - 2];
-    }, c4);
-    auto c6 = wide_layer<lw::F_L6 + 0 * 128, 16, 8, lw::T_L6 + 0, true, STORE, A_H0 + 96, A_MASK + 6>(pp, sink, mk, fa, from_b, c5);        // layers 6, 7
-    auto c7 = wide_layer<lw::F_L6 + 1 * 128, 16, 8, lw::T_L6 + 16, true, STORE, A_H0 + 112, A_MASK + 7>(pp, sink, mk, fb, from_a, c6);
-    // alpha head (row 0 of its tile), then the bottleneck (linear)
-    float sigma[2];
-    wide_tile<lw::F_ALPHA, 8, lw::T_ALPHA>(pp, from_b, c7);
-    if constexpr (STORE) {  // the view encoding comes back during the bottleneck layer
-        lvpe[0].issue(vm, act_tile + A_VPE * kFragBytes, lane * 16);
-        lvpe[1].issue(vm, act_tile + (A_VPE + 1) * kFragBytes, lane * 16);
-    }
-    auto c8 = wide_layer<lw::F_BOTT, 16, 8, lw::T_BOTT, false, STORE, A_BOTT, -1>(pp, sink, mk, fa, from_b, WKeepRow0{sigma});
-    half8 vpe9[2];
-    if constexpr (STORE) vpe9[0] = lvpe[0].get(vm), vpe9[1] = lvpe[1].get(vm); else vpe9[0] = vpe[0][0], vpe9[1] = vpe[1][0];
-    // view layer: [bottleneck ; view PE] -> 128, relu
-    auto c9 = wide_layer<lw::F_VIEW, 8, 9, lw::T_VIEW, true, STORE, A_V, A_MASK + 8>(pp, sink, mk, fb, [&](auto pt, auto kc) {
-        constexpr int k = decltype(kc)::value;
-        if constexpr (k < 8) return fa[decltype(pt)::value * kS + k]; else return vpe9[decltype(pt)::value];
-    }, c8);
-    wide_tile<lw::F_RGB, 4, lw::T_RGB>(pp, from_b, c9);                                                  // rgb rows 0..2
+
+    // ---- this lane's two query points (one per point tile) of the workgroup's first tile ----
+    PointWords cur[2] = {load_point<MODE>(a, blockIdx.x, wave, lane, 0), load_point<MODE>(a, blockIdx.x, wave, lane, 1)};
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        st.rebase();
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const f32x4& c = pp.acc[lw::T_RGB & 1][pt];
-        // the lane id is read afresh: neither it nor the point index is worth registers through the network
-        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const int64_t p = (int64_t)blockIdx.x * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (ln & 15);
-        if (p < a.M && (ln >> 4) == 0) a.raw[p] = make_float4(c[0], c[1], c[2], sigma[pt]);
+        for (int pt = 0; pt < 2; ++pt) {
+            float x[3], vd[3];
+            point_xyz<MODE>(cur[pt], x, vd);
+            encode_point(x, g, pe[pt]);
+            encode_view(vd, g, vpe[pt]);
+        }
+
+        WSink sink{nullptr, &vm};
+        const char* act_tile = nullptr;  // this wave's tile of saved activations (wave-uniform)
+        if constexpr (STORE) {
+            const int64_t wave_tile = tile * kWavesPerBlock + wave;
+            act_tile = a.act + (size_t)wave_tile * kActBlocks * kFragBytes;
+            sink.base = a.act + (size_t)wave_tile * kActBlocks * kFragBytes + lane * 16;
+            static_for<0, 2>([&](auto sc) {
+                constexpr int k = decltype(sc)::value;
+                sink.template put<A_PE + 2 * k>(pe[0][k]);
+                sink.template put<A_PE + 2 * k + 1>(pe[1][k]);
+            });
+            sink.template put<A_VPE>(vpe[0][0]);
+            sink.template put<A_VPE + 1>(vpe[1][0]);
+        }
+        const int enc_saved = vm.issued;  // the saved encodings are in memory once the queue is past this mark
+        FragLoad lpe[4], lvpe[2];
+        PointFetch nxt[2];
+        unsigned mk[4] = {0u, 0u, 0u, 0u};
+
+        st.start();
+        {
+            const f32x4 b = *(const f32x4*)(pp.bias);
+            pp.acc[0][0] = b, pp.acc[0][1] = b;
+        }
+        auto c0 = wide_layer<lw::F_L0, 16, 2, lw::T_L0, true, STORE, A_H0, A_MASK + 0>(pp, sink, mk, fa, from_pe, WNoPrev{});                     // layer 0
+        auto c1 = wide_layer<lw::F_L1 + 0 * 128, 16, 8, lw::T_L1 + 0, true, STORE, A_H0 + 16, A_MASK + 1>(pp, sink, mk, fb, from_a, c0);        // layers 1..4
+        auto c2 = wide_layer<lw::F_L1 + 1 * 128, 16, 8, lw::T_L1 + 16, true, STORE, A_H0 + 32, A_MASK + 2>(pp, sink, mk, fa, from_b, c1);
+        auto c3 = wide_layer<lw::F_L1 + 2 * 128, 16, 8, lw::T_L1 + 32, true, STORE, A_H0 + 48, A_MASK + 3>(pp, sink, mk, fb, from_a, c2);
+        if constexpr (STORE) {  // the point encoding comes back during layer 4 (blocks A_PE + 2k + pt)
+            vm.wait_until(enc_saved);
+            static_for<0, 4>([&](auto ic) { lpe[decltype(ic)::value].issue(vm, act_tile + (A_PE + decltype(ic)::value) * kFragBytes, lane * 16); });
+        }
+        auto c4 = wide_layer<lw::F_L1 + 3 * 128, 16, 8, lw::T_L1 + 48, true, STORE, A_H0 + 64, A_MASK + 4>(pp, sink, mk, fa, from_b, c3);
+        half8 pe5[2][2];
+        static_for<0, 4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, k = i >> 1, pt = i & 1;
+            if constexpr (STORE) pe5[pt][k] = lpe[i].get(vm); else pe5[pt][k] = pe[pt][k];
+        });
+        auto c5 = wide_layer<lw::F_L5, 16, 10, lw::T_L5, true, STORE, A_H0 + 80, A_MASK + 5>(pp, sink, mk, fb, [&](auto pt, auto kc) {         // layer 5: [PE ; h]
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < 2) return pe5[decltype(pt)::value][k]; else return fa[decltype(pt)::value * kS + k - 2];
+        }, c4);
+        auto c6 = wide_layer<lw::F_L6 + 0 * 128, 16, 8, lw::T_L6 + 0, true, STORE, A_H0 + 96, A_MASK + 6>(pp, sink, mk, fa, from_b, c5);        // layers 6, 7
+        auto c7 = wide_layer<lw::F_L6 + 1 * 128, 16, 8, lw::T_L6 + 16, true, STORE, A_H0 + 112, A_MASK + 7>(pp, sink, mk, fb, from_a, c6);
+        // alpha head (row 0 of its tile), then the bottleneck (linear)
+        float sigma[2];
+        wide_tile<lw::F_ALPHA, 8, lw::T_ALPHA>(pp, from_b, c7);
+        if constexpr (STORE) {  // the view encoding comes back during the bottleneck layer
+            lvpe[0].issue(vm, act_tile + A_VPE * kFragBytes, lane * 16);
+            lvpe[1].issue(vm, act_tile + (A_VPE + 1) * kFragBytes, lane * 16);
+        }
+        auto c8 = wide_layer<lw::F_BOTT, 16, 8, lw::T_BOTT, false, STORE, A_BOTT, -1>(pp, sink, mk, fa, from_b, WKeepRow0{sigma});
+        half8 vpe9[2];
+        if constexpr (STORE) vpe9[0] = lvpe[0].get(vm), vpe9[1] = lvpe[1].get(vm); else vpe9[0] = vpe[0][0], vpe9[1] = vpe[1][0];
+        // the next tile's rays and depths are requested before the last two layers (past the
+        // last tile the addresses are clamped to the last point and the words are not used)
+        nxt[0].template issue<MODE>(vm, a, tile + gridDim.x, wave, lane, 0);
+        nxt[1].template issue<MODE>(vm, a, tile + gridDim.x, wave, lane, 1);
+        // view layer: [bottleneck ; view PE] -> 128, relu
+        auto c9 = wide_layer<lw::F_VIEW, 8, 9, lw::T_VIEW, true, STORE, A_V, A_MASK + 8>(pp, sink, mk, fb, [&](auto pt, auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < 8) return fa[decltype(pt)::value * kS + k]; else return vpe9[decltype(pt)::value];
+        }, c8);
+        wide_tile<lw::F_RGB, 4, lw::T_RGB>(pp, from_b, c9);                                                  // rgb rows 0..2
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const f32x4& c = pp.acc[lw::T_RGB & 1][pt];
+            // the lane id is read afresh: neither it nor the point index is worth registers through the network
+            const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int64_t p = tile * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (ln & 15);
+            if (p < a.M && (ln >> 4) == 0) a.raw[p] = make_float4(c[0], c[1], c[2], sigma[pt]);
+        }
+        st.finish_pass();
+        cur[0] = nxt[0].get(vm), cur[1] = nxt[1].get(vm);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring loads requested for a pass that does not come
 }
 
 static int launch_fwd_wide(const FwdWideArgs& a, int mode, hipStream_t st, const char* what) {
-    const int64_t blocks = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
-    if (blocks > 0x7fffffffLL) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: too many points (%lld)", what, (long long)a.M);
+    const int64_t tiles = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
+    // persistent workgroups: one per CU (the ring and two waves per SIMD fill a CU), fewer for small calls
+    static thread_local int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: no current device", what);
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    const int64_t blocks = tiles < cus[dev] ? tiles : cus[dev];
     if (a.act)
         mlp_fwd_wide_kernel<0, true><<<(unsigned)blocks, 512, 0, st>>>(a);
     else if (mode == 0)

@@ -355,6 +355,7 @@ DEV void dw_stage_in(const DwStageSrc s, int64_t group, char* dst, int wave) {
     // 32-bit scalar operations per load
     const char* abase[G];
     const char* gbase[G];
+    const unsigned dst_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
 #pragma unroll
     for (int gt = 0; gt < G; ++gt) {
         int64_t wt = s.t_lo + group * G + gt;
@@ -383,7 +384,7 @@ DEV void dw_stage_in(const DwStageSrc s, int64_t group, char* dst, int wave) {
         // load n of an image = points 16 n .. 16 n + 15: block n of an input pair (one point tile
         // per block), the second 256 bytes of each lane half of a gradient pair
         const char* src = (is_x ? ab : gb) + (unsigned)(blk * kFragBytes + n * (is_x ? kFragBytes : 256));
-        glds16_untracked_sbase<true>(src, is_x ? s.off_x : one ? s.off_one : s.off_two, dst + (unsigned)(u * kFragBytes));
+        glds16_untracked_sbase<true>(src, is_x ? s.off_x : one ? s.off_one : s.off_two, dst_addr + (unsigned)(u * kFragBytes));
     }
 }
 
