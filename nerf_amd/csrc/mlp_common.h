@@ -93,6 +93,14 @@ struct VmQueue {
     DEV void wait_until(int mark) const { wait_vmcnt_n(issued - mark); }
 };
 
+// From here on this wave's fp32 -> fp16 conversions saturate: a result beyond the fp16 range
+// becomes +-65504 instead of +-inf (MODE.FP16_OVFL, bit 23 of hardware register 1; infinities and
+// NaNs pass through).  Same result as clamping the fp32 value to +-65504 before rounding, without
+// the two clamp instructions per pair of values.
+DEV void saturate_fp16_conversions() {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1u);
+}
+
 DEV f32x16 mfma(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }

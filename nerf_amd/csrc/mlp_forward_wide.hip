@@ -36,7 +36,8 @@ struct FwdWideArgs {
     const float* viewdirs;  // MODE 1: [M/S,3]
     float4* raw;            // [M] (r,g,b,sigma)
     char* act;              // training: saved activations [ceil(M/256)*8][kActBlocks][1 KiB], else null
-    int64_t M;              // points
+    int64_t M;              // points = n_rays * S
+    int64_t n_rays;
     int S;                  // points per ray
 };
 
@@ -125,16 +126,15 @@ struct WToFrag {
             // Round to fp16 first, then one packed max does the ReLU of both values (rounding is
             // monotone and keeps the sign, so this equals relu-then-round): two instructions per
             // pair instead of three, worth 1.7 % of the kernel, whose vector issue port is full.
-            // A hidden activation beyond the fp16 range (65504) becomes +inf rather than saturating.
+            // The conversion saturates at 65504 (saturate_fp16_conversions).
             const f32x2 x = {v[pt][2 * q], v[pt][2 * q + 1]};
             const half2v c = __builtin_convertvector(x, half2v);
             unsigned r;
             asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, c)));
             p = __builtin_bit_cast(half2v, r);
         } else {
-            const f32x2 x = {__builtin_amdgcn_fmed3f(v[pt][2 * q], -65504.f, 65504.f),
-                             __builtin_amdgcn_fmed3f(v[pt][2 * q + 1], -65504.f, 65504.f)};
-            p = __builtin_convertvector(x, half2v);
+            const f32x2 x = {v[pt][2 * q], v[pt][2 * q + 1]};
+            p = __builtin_convertvector(x, half2v);  // saturating
         }
         half8& f = dst0[pt * kStride + (TL >> 1)];
         constexpr int e = 4 * (TL & 1) + 2 * q;
@@ -261,25 +261,48 @@ struct PointWords {
     float s1, s2;
 };
 
+// Which ray a point belongs to, without a division per tile.  The first point of this wave in a
+// tile is base = tile * 256 + wave * 32 = q * S + r; the workgroup's next tile lies gridDim.x * 256
+// points further, which advances (q, r) by a fixed (dq, dr).  All of it is wave-uniform and runs
+// on the scalar unit; a lane adds its point number (< 32) to r and carries at most once when
+// S >= 32 (shorter rays take the division).
+struct RayCursor {
+    int64_t base, q, dq, step;
+    int r, dr, S;
+    DEV RayCursor(int64_t tile, int wave, int S_) : S(S_) {
+        base = tile * kPointsPerBlock + wave * kPointsPerWave;
+        q = base / S, r = (int)(base - q * S);
+        step = (int64_t)gridDim.x * kPointsPerBlock;
+        dq = step / S, dr = (int)(step - dq * S);
+    }
+    DEV void advance() {
+        base += step, q += dq, r += dr;
+        if (r >= S) r -= S, ++q;
+    }
+    DEV int64_t ray_of(int l) const { return S >= kPointsPerWave ? q + (r + l >= S ? 1 : 0) : (base + l) / S; }
+};
+
 template <int MODE>
-DEV void point_addresses(const FwdWideArgs& a, int64_t tile, int wave, int lane, int pt,
+DEV void point_addresses(const FwdWideArgs& a, const RayCursor& cur, int lane, int pt,
                          const float*& pa, const float*& pb, const float*& pz) {
-    const int64_t p = tile * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (lane & 15);
-    const int64_t pc = p < a.M ? p : a.M - 1;
-    const int64_t ray = pc / a.S;
-    if (MODE == 0) pa = a.rays + ray * a.width, pb = pa + 8, pz = a.z + pc;
+    const int l = 16 * pt + (lane & 15);
+    const int64_t p = cur.base + l, last = a.M - 1;
+    const int64_t pc = p < last ? p : last;       // past the end: the last point, never stored
+    int64_t ray = cur.ray_of(l);
+    ray = ray < a.n_rays - 1 ? ray : a.n_rays - 1;
+    if (MODE == 0) pa = a.rays + ray * a.width, pb = nullptr, pz = a.z + pc;
     else pa = a.pts + pc * 3, pb = a.viewdirs + ray * 3, pz = nullptr;
 }
 
 // Plain loads (first tile of a workgroup: nothing else is in flight yet).
 template <int MODE>
-DEV PointWords load_point(const FwdWideArgs& a, int64_t tile, int wave, int lane, int pt) {
+DEV PointWords load_point(const FwdWideArgs& a, const RayCursor& cur, int lane, int pt) {
     const float *pa, *pb, *pz;
-    point_addresses<MODE>(a, tile, wave, lane, pt, pa, pb, pz);
+    point_addresses<MODE>(a, cur, lane, pt, pa, pb, pz);
     PointWords w{};
     if (MODE == 0) {
         w.q4 = f32x4{pa[0], pa[1], pa[2], pa[3]}, w.q2a = f32x2{pa[4], pa[5]};
-        w.q2b = f32x2{pb[0], pb[1]}, w.s1 = pb[2], w.s2 = *pz;
+        w.q2b = f32x2{pa[8], pa[9]}, w.s1 = pa[10], w.s2 = *pz;
     } else {
         w.q2a = f32x2{pa[0], pa[1]}, w.s1 = pa[2], w.q2b = f32x2{pb[0], pb[1]}, w.s2 = pb[2];
     }
@@ -293,14 +316,14 @@ struct PointFetch {
     PointWords w;
     int mark;
     template <int MODE>
-    DEV void issue(VmQueue& vm, const FwdWideArgs& a, int64_t tile, int wave, int lane, int pt) {
+    DEV void issue(VmQueue& vm, const FwdWideArgs& a, const RayCursor& cur, int lane, int pt) {
         const float *pa, *pb, *pz;
-        point_addresses<MODE>(a, tile, wave, lane, pt, pa, pb, pz);
+        point_addresses<MODE>(a, cur, lane, pt, pa, pb, pz);
         if (MODE == 0) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.q4) : "v"(pa) : "memory");
             asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=v"(w.q2a) : "v"(pa) : "memory");
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(w.q2b) : "v"(pb) : "memory");
-            asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(w.s1) : "v"(pb) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off offset:32" : "=v"(w.q2b) : "v"(pa) : "memory");
+            asm volatile("global_load_dword %0, %1, off offset:40" : "=v"(w.s1) : "v"(pa) : "memory");
             asm volatile("global_load_dword %0, %1, off" : "=v"(w.s2) : "v"(pz) : "memory");
             vm.issued += 5;
         } else {
@@ -340,6 +363,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
     const int64_t ntiles = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
+    saturate_fp16_conversions();
 
     VmQueue vm;
     WideStream st(vm, a.packed, lds, wave, lane);
@@ -363,7 +387,8 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     WidePipe pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}};
 
     // ---- this lane's two query points (one per point tile) of the workgroup's first tile ----
-    PointWords cur[2] = {load_point<MODE>(a, blockIdx.x, wave, lane, 0), load_point<MODE>(a, blockIdx.x, wave, lane, 1)};
+    RayCursor where(blockIdx.x, wave, a.S);
+    PointWords cur[2] = {load_point<MODE>(a, where, lane, 0), load_point<MODE>(a, where, lane, 1)};
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         st.rebase();
@@ -431,8 +456,9 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
         if constexpr (STORE) vpe9[0] = lvpe[0].get(vm), vpe9[1] = lvpe[1].get(vm); else vpe9[0] = vpe[0][0], vpe9[1] = vpe[1][0];
         // the next tile's rays and depths are requested before the last two layers (past the
         // last tile the addresses are clamped to the last point and the words are not used)
-        nxt[0].template issue<MODE>(vm, a, tile + gridDim.x, wave, lane, 0);
-        nxt[1].template issue<MODE>(vm, a, tile + gridDim.x, wave, lane, 1);
+        where.advance();
+        nxt[0].template issue<MODE>(vm, a, where, lane, 0);
+        nxt[1].template issue<MODE>(vm, a, where, lane, 1);
         // view layer: [bottleneck ; view PE] -> 128, relu
         auto c9 = wide_layer<lw::F_VIEW, 8, 9, lw::T_VIEW, true, STORE, A_V, A_MASK + 8>(pp, sink, mk, fb, [&](auto pt, auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -455,6 +481,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
 
 static int launch_fwd_wide(const FwdWideArgs& a, int mode, hipStream_t st, const char* what) {
     const int64_t tiles = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
+    if (a.S > (1 << 24)) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: more than 2^24 points per ray (%d)", what, a.S);
     // persistent workgroups: one per CU (the ring and two waves per SIMD fill a CU), fewer for small calls
     static thread_local int cus[64] = {};
     int dev = 0;
@@ -489,7 +516,7 @@ NERF_API int nerf_mlp_forward_rays(const void* packed, const float* rays, int wi
     if (n_rays == 0) return 0;
     FwdWideArgs a{};
     a.packed = (const char*)packed, a.rays = rays, a.z = z, a.width = width;
-    a.raw = (float4*)raw, a.M = n_rays * S, a.S = S;
+    a.raw = (float4*)raw, a.M = n_rays * S, a.n_rays = n_rays, a.S = S;
     return launch_fwd_wide(a, 0, as_stream(stream), "nerf_mlp_forward_rays");
 }
 
@@ -502,7 +529,7 @@ NERF_API int nerf_mlp_forward_pts(const void* packed, const float* pts, const fl
     if (n == 0) return 0;
     FwdWideArgs a{};
     a.packed = (const char*)packed, a.pts = pts, a.viewdirs = viewdirs;
-    a.raw = (float4*)raw, a.M = n * S, a.S = S;
+    a.raw = (float4*)raw, a.M = n * S, a.n_rays = n, a.S = S;
     return launch_fwd_wide(a, 1, as_stream(stream), "nerf_mlp_forward_pts");
 }
 
@@ -522,6 +549,6 @@ NERF_API int nerf_mlp_forward_train(const void* packed, const float* rays, int w
     if (n_rays == 0) return 0;
     FwdWideArgs a{};
     a.packed = (const char*)packed, a.rays = rays, a.z = z, a.width = width;
-    a.raw = (float4*)raw, a.act = (char*)act, a.M = n_rays * S, a.S = S;
+    a.raw = (float4*)raw, a.act = (char*)act, a.M = n_rays * S, a.n_rays = n_rays, a.S = S;
     return launch_fwd_wide(a, 0, as_stream(stream), "nerf_mlp_forward_train");
 }

@@ -134,7 +134,7 @@ struct ChainPipe {
 };
 
 // What happens to a finished gradient tile: eight slices (two registers -> one packed dword,
-// clamped to the fp16 range, ANDed with the unit's ReLU mask bits) run between the MFMAs of the
+// saturated to the fp16 range by the conversion, multiplied by the unit's ReLU mask bits) run between the MFMAs of the
 // following tile; finished fragments are stored as blocks GBLK + 2*TL, +1 for the dW kernel.
 struct CNoPrev {
     static constexpr bool kActive = false;
@@ -147,18 +147,17 @@ struct CToFrags {
     GradSink sink;
     uint4v mk;    // the layer's mask bits for this lane's point (see MaskLoad)
     template <int S> DEV void slice(const f32x16& v) const {
-        const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * S], -65504.f, 65504.f),
-                         __builtin_amdgcn_fmed3f(v[2 * S + 1], -65504.f, 65504.f)};
-        half2v p = __builtin_convertvector(x, half2v);
+        const f32x2 x = {v[2 * S], v[2 * S + 1]};
+        half2v p = __builtin_convertvector(x, half2v);  // saturating (saturate_fp16_conversions)
         if constexpr (MASKED) {
             // registers 2S, 2S+1 of 32-unit tile TL = units 16 t + 4 g + r with t = 2 TL + (S >> 2),
             // g = h + 2 ((S >> 1) & 1), r = 2 (S & 1) (+1): pair i = 2 t + (S & 1) of the forward's
             // numbering, flags at bits (i & 15) and (i & 15) + 16 of dword i >> 4 (see MaskLoad)
             constexpr int i = 2 * (2 * TL + (S >> 2)) + (S & 1), piece = (S >> 1) & 1;
             const unsigned m = (mk[2 * piece + (i >> 4)] >> (i & 15)) & 0x00010001u;
-            unsigned keep;  // 0 / 0xFFFF per half (inline asm: the compiler scalarises packed u16 arithmetic)
-            asm("v_pk_sub_u16 %0, 0, %1" : "=v"(keep) : "v"(m));
-            p = __builtin_bit_cast(half2v, __builtin_bit_cast(unsigned, p) & keep);
+            unsigned kept;  // each half times its flag (inline asm: the compiler scalarises packed u16 arithmetic)
+            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(kept) : "v"(__builtin_bit_cast(unsigned, p)), "v"(m));
+            p = __builtin_bit_cast(half2v, kept);
         }
         half8& f = dst[2 * TL + (S >> 2)];
         f[2 * (S & 3)] = p[0], f[2 * (S & 3) + 1] = p[1];
@@ -207,6 +206,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
     const int64_t wave_tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    saturate_fp16_conversions();
 
     VmQueue vm;
     BwdStream st(vm, a.packed_bwd, lds, wave, lane);

@@ -380,6 +380,29 @@ def test_mlp_large_inputs_and_repack(gpu):
         np.testing.assert_array_equal(a, b)
 
 
+def test_mlp_hidden_activation_saturates_at_fp16_max(gpu):
+    """A hidden unit whose pre-activation exceeds the fp16 range is carried as 65504, not as inf:
+    the outputs equal those of a network whose unit sits exactly at 65504."""
+    from nerf_amd import ops
+    rng = np.random.default_rng(5)
+    ws = trained_like_weights(rng)
+    ws[0][:, 0] = 0
+    ws[1][0] = 1e6                                              # unit 0 of layer 0: relu(1e6)
+    ws[2][0, :] = rng.choice([-1., 1.], size=256) * 2. ** -13   # its fan-out, exact in fp16
+    pts = rng.uniform(-2., 2., size=(3, 40, 3)).astype(np.float32)
+    vd = rng.normal(size=(3, 3))
+    vd = (vd / np.linalg.norm(vd, axis=-1, keepdims=True)).astype(np.float32)
+    raw = ops.mlp_forward_pts(_model_from(ws, gpu).packed(), _t(pts, gpu), _t(vd, gpu)).cpu().numpy()
+    assert np.all(np.isfinite(raw))
+    ws_sat = [w.copy() for w in ws]
+    ws_sat[1][0] = 65504.
+    _check_raw(raw, orc.run_network(pts, vd, ws_sat, dtype=np.float64))
+    # and the unit matters: without it the outputs differ visibly
+    ws_off = [w.copy() for w in ws]
+    ws_off[1][0] = 0.
+    assert np.max(np.abs(raw - orc.run_network(pts, vd, ws_off, dtype=np.float64))) > 1e-2
+
+
 # ---------------------------------------------------------------------------------------------
 # end to end
 # ---------------------------------------------------------------------------------------------
