@@ -1,16 +1,19 @@
 // Alpha compositing along each ray (raw2outputs) as a wavefront-scan kernel: one 64-lane wave
 // per ray, one sample per lane per 64-sample chunk, exclusive transmittance product by a DPP
 // scan carried across chunks.  HBM-bound: raw (16 B/sample) and z (4 B/sample) are read once
-// as coalesced 1 KiB / 256 B wave transactions, weights written once.
+// as coalesced 1 KiB / 256 B wave transactions, weights written once; raw and weights are
+// streamed (read-once / written-once data does not displace the depths, which are read twice).
 #include "common.h"
 
 namespace nerf {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+typedef float comp_f32x4 __attribute__((ext_vector_type(4)));
+
 // What a lane reads for one sample: raw, depth, the next depth and the density noise.
 struct SampleIn {
-    float4 r;
+    comp_f32x4 r;
     float zz, znext, nz;
 };
 
@@ -18,79 +21,92 @@ __device__ __forceinline__ SampleIn load_sample(const float4* __restrict__ raw, 
                                                 const float* __restrict__ noise, int64_t row, int s, int S) {
     SampleIn in;
     const bool valid = s < S;
-    in.r = valid ? raw[row + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    in.r = comp_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (valid) in.r = __builtin_nontemporal_load((const comp_f32x4*)(raw + row + s));
     in.zz = valid ? z[row + s] : 0.f;
     in.znext = (s + 1 < S) ? z[row + s + 1] : 0.f;
     in.nz = (noise && valid) ? noise[row + s] : 0.f;
     return in;
 }
 
-// NCH = 64-sample chunks per ray, every load of the ray issued before the first scan (NCH x 1.3
-// KiB in flight per wave); NCH = 0: any S, chunk by chunk.
-template <int NCH>
+// NCH = 64-sample chunks per ray, R = rays a wave has in flight: every load of the R rays is
+// issued before the first scan (R x NCH x 1.3 KiB per wave, about 4 KiB: with less in flight the
+// kernel is bound by load latency, 4.0 instead of 6+ TB/s).  NCH = 0: any S, chunk by chunk.
+template <int NCH, int R>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float4* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d,
     int d_stride, int64_t n, int S, int white_bkgd, const float* __restrict__ noise,
     float noise_std, float* __restrict__ rgb_map, float* __restrict__ disp_map,
     float* __restrict__ acc_map, float* __restrict__ depth_map, float* __restrict__ weights) {
+    static_assert(NCH > 0 || R == 1, "the chunk-by-chunk path takes one ray at a time");
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t ray = wave0; ray < n; ray += nwaves) {
-        const int64_t row = ray * S;
-        SampleIn pre[NCH > 0 ? NCH : 1];
-        if constexpr (NCH > 0) {
+    for (int64_t ray0 = wave0 * R; ray0 < n; ray0 += nwaves * R) {
+        SampleIn pre[R][NCH > 0 ? NCH : 1];
+        float dir[R][3];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) pre[c] = load_sample(raw, z, noise, row, 64 * c + lane, S);
-        }
-        const float dx = rays_d[ray * d_stride], dy = rays_d[ray * d_stride + 1],
-                    dz = rays_d[ray * d_stride + 2];
-        const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
-        float carry = 1.0f;
-        float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
-        auto chunk = [&](int base, const SampleIn& in) {
-            const int s = base + lane;
-            const bool valid = s < S;
-            const float zz = in.zz;
-            float dist = (s + 1 < S) ? in.znext - zz : 1e10f;
-            dist = dist * norm;
-            float sig = in.r.w;
-            if (noise) sig = sig + in.nz * noise_std;
-            const float alpha = valid ? 1.0f - __expf(-fmaxf(sig, 0.f) * dist) : 0.f;
-            const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
-            const float incl = wave_scan_mul(t);
-            const float trans = carry * wave_shr1(1.0f, incl);
-            const float w = alpha * trans;
-            carry = carry * lane63(incl);
-            if (valid) {
-                if (weights) weights[row + s] = w;
-                sr += w * sigmoidf(in.r.x);
-                sg += w * sigmoidf(in.r.y);
-                sb += w * sigmoidf(in.r.z);
-                sd += w * zz;
-                sa += w;
-            }
-        };
-        if constexpr (NCH > 0) {
+        for (int q = 0; q < R; ++q) {
+            const int64_t ray = ray0 + q < n ? ray0 + q : n - 1;  // past the end: loaded, not used
+            if constexpr (NCH > 0) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) chunk(64 * c, pre[c]);
-        } else {
-            for (int base = 0; base < S; base += 64) chunk(base, load_sample(raw, z, noise, row, base + lane, S));
-        }
-        sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sd = wave_sum(sd),
-        sa = wave_sum(sa);
-        if (lane == 0) {
-            // disp = 1/max(1e-10, depth/acc); 0/0 stays NaN as in the reference's maximum().
-            const float q = sd / sa;
-            const float disp = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
-            if (white_bkgd) {
-                const float bg = 1.0f - sa;
-                sr += bg, sg += bg, sb += bg;
+                for (int c = 0; c < NCH; ++c) pre[q][c] = load_sample(raw, z, noise, ray * S, 64 * c + lane, S);
             }
-            rgb_map[ray * 3] = sr, rgb_map[ray * 3 + 1] = sg, rgb_map[ray * 3 + 2] = sb;
-            if (disp_map) disp_map[ray] = disp;
-            if (acc_map) acc_map[ray] = sa;
-            if (depth_map) depth_map[ray] = sd;
+            dir[q][0] = rays_d[ray * d_stride], dir[q][1] = rays_d[ray * d_stride + 1], dir[q][2] = rays_d[ray * d_stride + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int64_t ray = ray0 + q;
+            if (ray >= n) break;  // wave-uniform
+            const int64_t row = ray * S;
+            const float dx = dir[q][0], dy = dir[q][1], dz = dir[q][2];
+            const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+            float carry = 1.0f;
+            float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+            auto chunk = [&](int base, const SampleIn& in) {
+                const int s = base + lane;
+                const bool valid = s < S;
+                const float zz = in.zz;
+                float dist = (s + 1 < S) ? in.znext - zz : 1e10f;
+                dist = dist * norm;
+                float sig = in.r[3];
+                if (noise) sig = sig + in.nz * noise_std;
+                const float alpha = valid ? 1.0f - __expf(-fmaxf(sig, 0.f) * dist) : 0.f;
+                const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
+                const float incl = wave_scan_mul(t);
+                const float trans = carry * wave_shr1(1.0f, incl);
+                const float w = alpha * trans;
+                carry = carry * lane63(incl);
+                if (valid) {
+                    if (weights) __builtin_nontemporal_store(w, weights + row + s);
+                    sr += w * sigmoidf(in.r[0]);
+                    sg += w * sigmoidf(in.r[1]);
+                    sb += w * sigmoidf(in.r[2]);
+                    sd += w * zz;
+                    sa += w;
+                }
+            };
+            if constexpr (NCH > 0) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) chunk(64 * c, pre[q][c]);
+            } else {
+                for (int base = 0; base < S; base += 64) chunk(base, load_sample(raw, z, noise, row, base + lane, S));
+            }
+            sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sd = wave_sum(sd),
+            sa = wave_sum(sa);
+            if (lane == 0) {
+                // disp = 1/max(1e-10, depth/acc); 0/0 stays NaN as in the reference's maximum().
+                const float qd = sd / sa;
+                const float disp = 1.0f / ((qd != qd) ? qd : fmaxf(1e-10f, qd));
+                if (white_bkgd) {
+                    const float bg = 1.0f - sa;
+                    sr += bg, sg += bg, sb += bg;
+                }
+                rgb_map[ray * 3] = sr, rgb_map[ray * 3 + 1] = sg, rgb_map[ray * 3 + 2] = sb;
+                if (disp_map) disp_map[ray] = disp;
+                if (acc_map) acc_map[ray] = sa;
+                if (depth_map) depth_map[ray] = sd;
+            }
         }
     }
 }
@@ -210,18 +226,21 @@ NERF_API int nerf_composite_fwd(const float* raw, const float* z, const float* r
     NERF_REQUIRE(((uintptr_t)raw & 15) == 0, "nerf_composite_fwd: raw must be 16-byte aligned");
     if (n == 0) return 0;
     if (noise_std <= 0.f) noise = nullptr;
-    const int64_t want = (n + 3) / 4;
-    const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
-    auto launch = [&](auto kernel) {
+    // one wave per group of R rays, 4 waves per block, and as many blocks as that takes: waves
+    // that start in ray order keep the chip's reads and writes in one moving window (measured on
+    // 1 M rays of 192 samples: 6.0 TB/s against 5.2 TB/s with 32768 blocks walking 8 groups each)
+    auto launch = [&](auto kernel, int R) {
+        const int64_t want = (n + 4 * R - 1) / (4 * R);
+        const unsigned blocks = (unsigned)(want < 0x40000000 ? want : 0x40000000);
         kernel<<<blocks, 256, 0, as_stream(stream)>>>((const float4*)raw, z, rays_d, d_stride, n, S, white_bkgd, noise,
                                                         noise_std, rgb_map, disp_map, acc_map, depth_map, weights);
     };
     const int nch = (S + 63) / 64;
-    if (nch == 1) launch(composite_fwd_kernel<1>);
-    else if (nch == 2) launch(composite_fwd_kernel<2>);
-    else if (nch == 3) launch(composite_fwd_kernel<3>);
-    else if (nch == 4) launch(composite_fwd_kernel<4>);
-    else if (nch <= 6) launch(composite_fwd_kernel<6>);
-    else launch(composite_fwd_kernel<0>);
+    if (nch == 1) launch(composite_fwd_kernel<1, 2>, 2);
+    else if (nch == 2) launch(composite_fwd_kernel<2, 2>, 2);
+    else if (nch == 3) launch(composite_fwd_kernel<3, 1>, 1);
+    else if (nch == 4) launch(composite_fwd_kernel<4, 1>, 1);
+    else if (nch <= 6) launch(composite_fwd_kernel<6, 1>, 1);
+    else launch(composite_fwd_kernel<0, 1>, 1);
     return check_launch("nerf_composite_fwd");
 }
