@@ -224,7 +224,7 @@ def _assert_samples(s, ref, tol, knife):
 
 
 @pytest.mark.parametrize("nb,ns,det", [(63, 128, True), (63, 128, False), (255, 128, True), (5, 7, False),
-                                       (2, 1, True)])
+                                       (2, 1, True), (64, 64, True), (100, 33, False), (300, 64, True)])
 def test_sample_pdf(gpu, nb, ns, det):
     from nerf_amd.run_nerf_helpers import sample_pdf
     rng = np.random.default_rng(nb * 7 + ns)
@@ -257,7 +257,7 @@ def test_sample_pdf_known_answers(gpu):
 
 
 @pytest.mark.parametrize("Sc,Si,det", [(64, 128, True), (64, 128, False), (256, 128, True), (5, 3, False),
-                                       (64, 100, False)])
+                                       (64, 100, False), (128, 64, True), (65, 128, True), (300, 128, False)])
 def test_resample_merge(gpu, Sc, Si, det):
     from nerf_amd import ops
     rng = np.random.default_rng(Sc + Si)
@@ -274,6 +274,23 @@ def test_resample_merge(gpu, Sc, Si, det):
     assert np.all(np.diff(zo, axis=-1) >= 0), "merged depths must be sorted"
     np.testing.assert_array_equal(zo, np.sort(np.concatenate([z, zs], -1), -1))
     np.testing.assert_allclose(zstd, np.std(zs.astype(np.float64), -1), atol=FP32_TOL)
+
+
+@pytest.mark.parametrize("Sc,Si,det", [(64, 128, True), (100, 64, False)])
+def test_resample_merge_many_rays_per_wave(gpu, Sc, Si, det):
+    """More rays than resident waves: a wave walks several rays (reading the next one's row
+    ahead); the result of every ray equals that of the same ray processed in a small call."""
+    from nerf_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(Sc)
+    n = 70001
+    z = torch.sort(torch.rand((n, Sc), generator=g, device=gpu) * 4 + 2, dim=-1).values
+    w = torch.rand((n, Sc), generator=g, device=gpu) ** 6
+    u = None if det else torch.rand((n, Si), generator=g, device=gpu)
+    zo, zs, zstd = ops.resample_merge(z, w, Si, det=det, u=u)
+    for lo, hi in ((0, 300), (32768, 33000), (69900, 70001)):
+        zo1, zs1, zstd1 = ops.resample_merge(z[lo:hi].contiguous(), w[lo:hi].contiguous(), Si, det=det,
+                                            u=None if det else u[lo:hi].contiguous())
+        assert torch.equal(zo[lo:hi], zo1) and torch.equal(zs[lo:hi], zs1) and torch.equal(zstd[lo:hi], zstd1)
 
 
 # ---------------------------------------------------------------------------------------------
