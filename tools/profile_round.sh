@@ -1,11 +1,11 @@
 #!/bin/bash
 # Profile set of a round (run on the GPU box from the repository root, e.g. through gpurun):
 # kernel stats of the default bench, three PMC passes over render + training kernels, the
-# un-profiled line.  Results land in gpurun_out/r01b; tools/pmc_summary.py sums the counters.
+# un-profiled line.  Results land in gpurun_out/r01d; tools/pmc_summary.py sums the counters.
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/r01c
+O=$R/gpurun_out/r01d
 rm -rf $O && mkdir -p $O
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-rays 0 > $O/bench_under_rocprof.json 2> $O/stats.err
 B="python3 $R/bench.py --steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --rays 262144"
