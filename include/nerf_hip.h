@@ -107,8 +107,10 @@ int nerf_mlp_pack(const float* const* params, void* packed, nerf_stream_t stream
 /* run_network + the Keras model call (run_nerf.py:209-214; run_nerf_helpers.py:22-56, :89-112,
  * :216-223) with the query points formed on the fly as o + d*z (render_rays).  Positional
  * encoding (L=10 points, L=4 view directions) is computed in-kernel; matmuls are fp16 MFMA with
- * fp32 accumulation.  rays [n_rays,width>=11], z [n_rays,S] -> raw [n_rays,S,4] = (r,g,b,sigma)
- * pre-activation. */
+ * fp32 accumulation.  Hidden activations are carried in fp16 and saturate at 65504 (a unit
+ * that exceeds the fp16 range is held at the largest finite value, it does not become inf).
+ * rays [n_rays,width>=11], z [n_rays,S] -> raw [n_rays,S,4] = (r,g,b,sigma) pre-activation.
+ * At most 2^24 samples per ray. */
 int nerf_mlp_forward_rays(const void* packed, const float* rays, int width, const float* z,
                           int64_t n_rays, int S, float* raw, nerf_stream_t stream);
 
