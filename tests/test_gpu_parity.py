@@ -378,6 +378,29 @@ def test_mlp_forward_rays_equals_pts(gpu):
     assert torch.equal(raw_r, raw_p)
 
 
+@pytest.mark.parametrize("S", [5, 31, 33, 300])
+def test_mlp_many_tiles_per_workgroup(gpu, S):
+    """More 256-point tiles than workgroups, rays shorter and longer than a wave's 32 points and
+    a ragged last tile: every point's output equals that of the same point evaluated alone with
+    its ray's direction (one point per ray), and that of a small call on a slice of the rays."""
+    from nerf_amd import ops
+    rng = np.random.default_rng(S)
+    model = _model_from(trained_like_weights(rng), gpu)
+    n = (256 * 256 * 2 + 1234) // S + 1          # > 2 tiles per workgroup on a 256-CU chip
+    rb = synthetic_rays(n, seed=S)
+    rays = _t(rb, gpu)
+    z = ops.sample_z(rays, S)
+    raw = ops.mlp_forward_rays(model.packed(), rays, z)
+    assert raw.shape == (n, S, 4)
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]).reshape(-1, 1, 3).contiguous()
+    vd = rays[:, None, 8:11].expand(n, S, 3).reshape(-1, 3).contiguous()
+    raw_p = ops.mlp_forward_pts(model.packed(), pts, vd)
+    assert torch.equal(raw.reshape(-1, 4), raw_p.reshape(-1, 4))
+    for lo, hi in ((0, 7), (n // 2, n // 2 + 50), (n - 3, n)):
+        raw_s = ops.mlp_forward_rays(model.packed(), rays[lo:hi].contiguous(), z[lo:hi].contiguous())
+        assert torch.equal(raw[lo:hi], raw_s)
+
+
 def test_mlp_large_inputs_and_repack(gpu):
     """Far-away points (|x| ~ 100, sin(512x) needs exact range reduction) and weight updates."""
     from nerf_amd import ops
