@@ -189,6 +189,46 @@ def test_mlp_backward(gpu, n, S):
         assert torch.allclose(b, 2 * a, rtol=1e-3, atol=1e-12)
 
 
+def test_mlp_backward_many_tiles_is_the_sum_of_its_slices(gpu):
+    """A batch of more 256-point tiles than workgroups (the saving forward's workgroups each walk
+    several tiles): outputs equal inference bit for bit, and the weight gradients of the whole
+    batch equal the sum of the gradients of its two halves, computed by separate calls."""
+    from nerf_amd import ops
+    from nerf_amd.run_nerf_helpers import init_nerf_model
+    rng = np.random.default_rng(21)
+    m = init_nerf_model(8, 256, 63, 27, 4, [4], True, device=gpu)
+    m.set_weights(trained_like_weights(rng))
+    n, S = 1100, 192                       # 211,200 points = 825 tiles
+    rays = _t(synthetic_rays(n, seed=8), gpu)
+    z = ops.sample_z(rays, S)
+    g = torch.Generator(device=gpu).manual_seed(1)
+    d_raw = torch.randn((n, S, 4), generator=g, device=gpu) * 1e-3
+    pb = torch.empty((ops.packed_bwd_bytes(),), dtype=torch.uint8, device=gpu)
+    ops.mlp_pack_bwd([p.detach() for p in m.params], pb)
+    part = torch.empty((ops.partial_bytes(),), dtype=torch.uint8, device=gpu)
+
+    def fwd_bwd(lo, hi):
+        r, zz, dr = rays[lo:hi].contiguous(), z[lo:hi].contiguous(), d_raw[lo:hi].contiguous()
+        pts = (hi - lo) * S
+        act = torch.zeros((ops.act_bytes(pts),), dtype=torch.uint8, device=gpu)
+        raw = ops.mlp_forward_train(m.packed(), r, zz, act)
+        gbuf = torch.empty((ops.grad_bytes(pts),), dtype=torch.uint8, device=gpu)
+        grads = [torch.zeros_like(p) for p in m.params]
+        ops.mlp_backward(pb, act, dr, 4096.0, gbuf, part, grads)
+        return raw, grads
+
+    raw, full = fwd_bwd(0, n)
+    assert torch.equal(raw, ops.mlp_forward_rays(m.packed(), rays, z))
+    h = 601                                # the halves do not end on a tile boundary
+    raw_a, ga = fwd_bwd(0, h)
+    raw_b, gb = fwd_bwd(h, n)
+    assert torch.equal(raw_a, raw[:h]) and torch.equal(raw_b, raw[h:])
+    for i, (gf, x, y) in enumerate(zip(full, ga, gb)):
+        gs = x + y
+        err = float((gf - gs).norm() / gs.norm().clamp_min(1e-20))
+        assert err < 1e-4, f"tensor {i}: {err}"
+
+
 def test_mse_and_keras_adam(gpu):
     from nerf_amd import training
     from nerf_amd.run_nerf_helpers import img2mse, mse2psnr
