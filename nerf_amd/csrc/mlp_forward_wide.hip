@@ -7,8 +7,8 @@
 // are persistent (one per CU, tiles of 256 points dealt round-robin): while a tile's last layers
 // run, the weight stream already refills the ring for the next tile and the next tile's rays
 // and depths are fetched, so a CU never waits for a workgroup launch, a cold ring or its inputs
-// (measured before: 3.0 us from workgroup start to the first chunk + 2.2 us between workgroups,
-// of 52.6 us per tile).  A layer is computed
+// (with one workgroup per tile that cost 3.0 us from workgroup start to the first chunk + 2.2 us
+// between workgroups, of 52.6 us per tile).  A layer is computed
 // one 16-row output tile at a time: one A fragment per k-step feeds two v_mfma_f32_16x16x32_f16
 // (one per point tile), 2 x 4 fp32 accumulator registers seeded with the biases.  A finished tile
 // is converted (fp16 rounding, then a packed ReLU) in four slices placed between the MFMAs of the
