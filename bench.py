@@ -39,6 +39,34 @@ N_RAYS = 1024 * 1024
 N_SAMPLES, N_IMPORTANCE = 64, 128
 
 
+def pmc_traffic_per_launch(kernel="mlp_fwd_wide_kernel<0, false>"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes
+    (profiles/r01_pmc_summary.txt: FETCH_SIZE and WRITE_SIZE in KiB summed over n dispatches of the
+    same launch shapes as the default bench: 131072-ray chunks, coarse and fine launches in equal
+    number).  FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes).  None when
+    the summary is absent or unreadable: bench.py itself cannot collect counters."""
+    try:
+        text = open(os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")).read()
+    except OSError:
+        return None
+    got = {}
+    for section in text.split("== pass")[1:]:
+        lines = section.splitlines()
+        for i, line in enumerate(lines):
+            if kernel in line and "n=" in line:
+                n = int(line.split("n=")[1].split()[0])
+                for follow in lines[i + 1:]:
+                    if not follow.startswith("    "):
+                        break
+                    parts = follow.split()
+                    if parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                        got[parts[0]] = float(parts[1]) * 1024.0 / n
+                break
+    if "FETCH_SIZE" not in got or "WRITE_SIZE" not in got:
+        return None
+    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]
+
+
 def synthetic_batch(n, seed, device):
     """Origins on a radius-4 sphere, directions toward uniform targets in [-1,1]^3, not normalised."""
     g = torch.Generator(device="cpu")
@@ -219,7 +247,10 @@ def main():
                        "rays_per_gpu": a.rays, "chunk": a.chunk, "networks": "2 x (D=8, W=256, skip 4, view head), random init",
                        "parallelism": f"ray-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         # bytes per launch from the committed counter passes (same launch shapes), not live
+                         "traffic": pmc_traffic_per_launch() if a.chunk == 131072 and a.rays % a.chunk == 0 else None,
+                         "algorithmic_bytes_per_launch": (mlp_points // max(1, len(timing))) * 20,
                          "kernel": "mlp_fwd_wide_kernel", "launches": len(timing),
                          "avg_launch_ms": round(mlp_ms / max(1, len(timing)), 4),
                          "flop_per_point": FLOP_PER_POINT, "points_per_launch": mlp_points // max(1, len(timing)),
