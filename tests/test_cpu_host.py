@@ -180,3 +180,17 @@ def test_ray_sharding_two_ranks_gloo(tmp_path):
     s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_bench_reads_traffic_from_committed_counter_summary():
+    """bench.py's roofline.traffic comes from profiles/r01_pmc_summary.txt: it parses, and lies
+    within 25 % of the kernel's algorithmic bytes per launch (20 B/point, 16,777,216 points)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.pmc_traffic_per_launch()
+    assert t is not None and 0.75 < t / (16777216 * 20) < 1.25
+    assert bench.pmc_traffic_per_launch("no_such_kernel") is None
