@@ -118,8 +118,6 @@ def train_leg(a, kw_train, models, dev, rank, world, fence):
     g = torch.Generator(device="cpu")
     g.manual_seed(77 + rank)
     target = torch.rand((a.n_rand, 3), generator=g).to(dev)
-    for m in models.values():
-        m.grad_scale = float(2 ** round(np.log2(48.0 * a.n_rand * world * 16)))
     opt = training.Adam(training.ExponentialDecay(5e-4, 500 * 1000, 0.1))
     fn = lambda r: render(1, 1, 1., chunk=1024 * 32, rays=r, near=2., far=6., retraw=True, **kw)
     for _ in range(3):

@@ -171,19 +171,37 @@ size_t nerf_mlp_packed_bwd_bytes(void);
 int nerf_mlp_pack_bwd(const float* const* params, void* packed_bwd, nerf_stream_t stream);
 
 /* Scratch sizes of nerf_mlp_backward: fp16 layer gradients for n_points, and the fp32
- * partial-sum buffer (fixed size). */
+ * partial-sum buffer (fixed size for the current device: a status block, the summed
+ * accumulator tiles and one set of partial tiles per workgroup of the weight-gradient kernel). */
 size_t nerf_mlp_grad_bytes(int64_t n_points);
 size_t nerf_mlp_partial_bytes(void);
+
+/* Status bits of the last nerf_mlp_backward that used a given `partial` buffer. */
+#define NERF_GRAD_SATURATED 1 /* a layer gradient reached the fp16 maximum, or was inf / NaN  */
+#define NERF_GRAD_UNDERFLOW 2 /* d_raw was non-zero, yet every fp16 layer gradient was denormal */
 
 /* Gradient of the network parameters (tape.gradient(loss, grad_vars), run_nerf.py:825, restricted
  * to one network): d_raw [n_points,4] -> grads: HOST array of 24 device pointers in get_weights()
  * order, each shaped like its parameter.  `act` is what nerf_mlp_forward_train saved for the same
- * points.  The chain runs in fp16 with fp32 accumulation; d_raw is multiplied by `gscale` first
- * (choose it so that gscale*|d_raw| is around 1e-2..1e2) and the result divided by it.
+ * points.  The chain runs in fp16 with fp32 accumulation; d_raw is multiplied by a power of two
+ * first and the result divided by it.  gscale <= 0 (the normal use): the factor is formed on the
+ * device from max|d_raw| so that the largest scaled element lies in [1024, 2048) -- no host
+ * synchronisation.  gscale > 0: the caller's factor is used as given.  Either way the call records
+ * whether a layer gradient saturated the fp16 range (or was not finite) or everything sank below
+ * the smallest normal fp16; when either happened the gradients are written as NaN, never as
+ * plausible numbers (read the bits with nerf_mlp_backward_status).
+ * Weight gradients are summed in a fixed order: the same inputs give the same bits.
  * accumulate != 0 adds into grads instead of overwriting.  No gradient flows to rays or depths. */
 int nerf_mlp_backward(const void* packed_bwd, const void* act, const float* d_raw, int64_t n_points,
                       float gscale, void* gbuf, void* partial, float* const* grads, int accumulate,
                       nerf_stream_t stream);
+
+/* Reads the status block the last nerf_mlp_backward left in `partial` (enqueued on `stream`
+ * behind it; waits for the stream): *flags = NERF_GRAD_* bits, *gscale_used, *absmax_d_raw
+ * (either may be NULL).  The reference's counterpart is upstream's tf.debugging.check_numerics on
+ * the outputs of render_rays (NERFCO.nerf_renderer, source absent from the reference tree). */
+int nerf_mlp_backward_status(const void* partial, int* flags, float* gscale_used, float* absmax_d_raw,
+                             nerf_stream_t stream);
 
 /* img2mse and its gradient (run_nerf_helpers.py:11; run_nerf.py:781,:809): adds
  * sum((x-y)^2)*inv_count to *loss (which the caller zeroes; may be NULL) and writes

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include "../../include/nerf_hip.h"
 
 #define NERF_API extern "C" __attribute__((visibility("default")))
@@ -29,6 +30,19 @@ inline int check_launch(const char* what) {
 }
 
 inline hipStream_t as_stream(nerf_stream_t s) { return (hipStream_t)s; }
+
+// Compute units of the current device (cached per device; 0 when there is no device to ask).
+inline int device_cu_count() {
+    static thread_local int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
 
 constexpr int kWave = 64;
 

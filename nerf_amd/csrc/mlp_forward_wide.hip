@@ -483,15 +483,9 @@ static int launch_fwd_wide(const FwdWideArgs& a, int mode, hipStream_t st, const
     const int64_t tiles = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
     if (a.S > (1 << 24)) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: more than 2^24 points per ray (%d)", what, a.S);
     // persistent workgroups: one per CU (the ring and two waves per SIMD fill a CU), fewer for small calls
-    static thread_local int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: no current device", what);
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    const int64_t blocks = tiles < cus[dev] ? tiles : cus[dev];
+    const int cus = device_cu_count();
+    if (cus <= 0) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: no current device", what);
+    const int64_t blocks = tiles < cus ? tiles : cus;
     if (a.act)
         mlp_fwd_wide_kernel<0, true><<<(unsigned)blocks, 512, 0, st>>>(a);
     else if (mode == 0)

@@ -13,16 +13,75 @@
 //     The contraction runs over points, which the stored fragments keep on the lane, so every
 //     operand is rebuilt with the transposing LDS read (ds_read_b64_tr_b16).  One workgroup
 //     owns a (layer, point range) pair, keeps the whole dW^T of the layer in accumulators
-//     (wave w = output tile w) and adds it to a global fp32 buffer once at the end.  Bias
+//     (wave w = output tile w) and stores it as its own partial tiles once at the end; a small
+//     kernel then adds the partial tiles of a job in workgroup order (no atomics: the same inputs
+//     give the same bits).  Bias
 //     gradients are the sums of the gradient operand over the points.  Layers whose input is
 //     a concatenation (layer 5, view layer) and heads that share an input (bottleneck, alpha) are
 //     one job each, so every saved block is read once.  HBM-bound: ~9.9 KB/point read for
 //     1.19 MFLOP/point.
-//  3. mlp_grad_unpack_kernel -- accumulator-ordered partial sums -> the 24 arrays, times 1/gscale.
+//  3. mlp_grad_unpack_kernel -- accumulator-ordered sums -> the 24 arrays, times 1/gscale.
+//
+// The gradient scale.  The chain carries gradients in fp16, so d raw is multiplied by a power of
+// two on entry and the result divided by it on exit.  By default the factor is formed on the
+// device from max |d raw| (draw_absmax_kernel) so that the largest scaled element lies in
+// [1024, 2048): 32x of headroom to the fp16 maximum for growth inside the chain, 2^24 of range
+// below it before the smallest normal number.  The weight-gradient kernel, which reads every stored
+// layer gradient anyway, records the largest fp16 bit pattern it saw; the unpack kernel turns that
+// into a status word (saturated / non-finite, or everything below the smallest normal number) and,
+// when it is set, writes NaN instead of numbers nobody should trust.
 #include "mlp_common.h"
 #include "mlp_layout_wide.h"
 
 namespace nerf {
+
+// ---------------------------------------------------------------------------------------------
+// status block (the first kStatusBytes of the caller's `partial` scratch) and the gradient scale
+// ---------------------------------------------------------------------------------------------
+constexpr int kStatusBytes = 256;
+enum StatusWord {
+    ST_ABSMAX = 0,   // in: bit pattern of max |d raw| (a non-negative float orders like its bits; NaN sorts above inf)
+    ST_YMAX = 1,     // in: largest |fp16| bit pattern among the stored layer gradients
+    ST_FLAGS = 4,    // out: NERF_GRAD_* bits
+    ST_GSCALE = 5,   // out: the factor that was applied (float)
+    ST_ABSMAX_OUT = 6,  // out: max |d raw| (float)
+    ST_YMAX_OUT = 7,    // out: copy of ST_YMAX
+};
+
+// The power of two that brings mx into [1024, 2048); 1 when mx is zero, denormal or not finite.
+__host__ __device__ inline float auto_gscale(unsigned absmax_bits) {
+    const int e = (int)((absmax_bits >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.0f;
+    int f = 127 + 10 - (e - 127);
+    f = f < 1 ? 1 : f > 254 ? 254 : f;
+    const unsigned bits = (unsigned)f << 23;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(float, bits);
+#else
+    float r;
+    memcpy(&r, &bits, sizeof r);
+    return r;
+#endif
+}
+
+__global__ __launch_bounds__(256) void draw_absmax_kernel(const float4* __restrict__ d_raw, int64_t n,
+                                                          unsigned* __restrict__ status) {
+    unsigned m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = d_raw[i];
+        const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+        const unsigned c = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+        const unsigned q = ab > cd ? ab : cd;
+        m = m > q ? m : q;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off);
+        m = m > o ? m : o;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(status + ST_ABSMAX, m);
+}
 
 // ---------------------------------------------------------------------------------------------
 // backward weight stream
@@ -125,7 +184,8 @@ struct ChainArgs {
     const float4* d_raw;  // [M]
     char* gbuf;           // [wave tiles][kGradBlocks][1 KiB]
     int64_t M;
-    float gscale;
+    float gscale;         // > 0: the caller's factor; otherwise formed from status[ST_ABSMAX]
+    const unsigned* status;
 };
 
 struct ChainPipe {
@@ -222,11 +282,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
     if (p < a.M && h == 0) g = a.d_raw[p];
     half8 dC = {0, 0, 0, 0, 0, 0, 0, 0}, dA = {0, 0, 0, 0, 0, 0, 0, 0};
     {
-        const float lim = 65504.f;
-        dC[0] = (_Float16)__builtin_amdgcn_fmed3f(g.x * a.gscale, -lim, lim);
-        dC[1] = (_Float16)__builtin_amdgcn_fmed3f(g.y * a.gscale, -lim, lim);
-        dC[2] = (_Float16)__builtin_amdgcn_fmed3f(g.z * a.gscale, -lim, lim);
-        dA[0] = (_Float16)__builtin_amdgcn_fmed3f(g.w * a.gscale, -lim, lim);
+        const float gs = a.gscale > 0.f ? a.gscale : auto_gscale(a.status[ST_ABSMAX]);
+        // saturating conversions (a NaN stays a NaN and is reported by the status word)
+        const half2v xy = __builtin_convertvector(f32x2{g.x * gs, g.y * gs}, half2v);
+        const half2v zw = __builtin_convertvector(f32x2{g.z * gs, g.w * gs}, half2v);
+        dC[0] = xy[0], dC[1] = xy[1], dC[2] = zw[0];
+        dA[0] = zw[1];
     }
     sink.template put<G_DA>(dA);
     sink.template put<G_DC>(dC);
@@ -280,14 +341,19 @@ struct DwJob {
     int y_blk, y1_blk;   // gradient segments: first block in the gradient buffer
     int y_k;             // blocks of y (1 or even)
     int n_out;           // output tiles (<= 8): wave w owns output tile w
-    int tile0;           // first 32x32 tile of this job in the partial-sum buffer
+    int tile0;           // first 32x32 tile of this job in the summed buffer
+    int n_acc;           // accumulator tiles of this job (what one workgroup stores)
+    int slab0;           // first tile of this job's per-workgroup partial tiles: workgroup slice s stores
+                         // tiles [slab0 + s * n_acc, slab0 + (s + 1) * n_acc)
+    int used;            // workgroups of this job that own at least one wave tile (the others store nothing)
     int wg0, wgs;        // workgroups [wg0, wg0 + wgs) split the wave tiles of this job
 };
 
 struct DwArgs {
     const char* act;
     const char* gbuf;
-    float* gperm;        // [tiles][16 regs][64 lanes]
+    float* slabs;        // [partial tiles][16 regs][64 lanes]: every workgroup's own sums
+    unsigned* status;
     int64_t wave_tiles;
     DwJob job[kNumJobs];
 #ifdef DW_STAMPS  // diagnostic build only: per-workgroup (begin, end, job) timestamps
@@ -440,6 +506,19 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
     // 8 points of output row (lane & 31), so one fp32 register per lane takes the sum (v_dot2 with
     // ones) and the two lane halves meet in the atomic add at the end.
     float bsum = 0.f, bsum_r = 0.f;
+    // largest |fp16| bit pattern among the gradient operands this wave reads (two per dword): the
+    // status word's evidence that nothing in the chain saturated, became NaN or sank into denormals
+    unsigned ymax = 0u;
+    auto track = [&](const half8& v) {
+        typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+        typedef unsigned uint4t __attribute__((ext_vector_type(4)));
+        const uint4t w = __builtin_bit_cast(uint4t, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const ushort2v cur = __builtin_bit_cast(ushort2v, w[j] & 0x7fff7fffu);
+            ymax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ushort2v, ymax), cur));
+        }
+    };
     auto point_sum = [](const half8& v, float s) {
         const half2v one = {(_Float16)1.f, (_Float16)1.f};
 #pragma unroll
@@ -485,6 +564,7 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
                                     const half8 ya = tr_operand(stage + NX * kTileImgBytes, kp, lane, y_one);
                                     acc[0] = mfma(ya, tr_operand(stage + wave * kTileImgBytes, kp, lane, false), acc[0]);
                                     if constexpr (BIAS) bsum = point_sum(ya, bsum);
+                                    if (wave == 0) track(ya);
                                 }
                             }
                         }
@@ -525,9 +605,11 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
                                     __builtin_amdgcn_sched_barrier(0);
                                 });
                                 if constexpr (BIAS) bsum = point_sum(ya[1], point_sum(ya[0], bsum));
+                                track(ya[0]), track(ya[1]);
                                 if constexpr (NY1) {
                                     accr = mfma(yr[1], xr[1], mfma(yr[0], xr[0], accr));
                                     if constexpr (BIAS) bsum_r = point_sum(yr[1], point_sum(yr[0], bsum_r));
+                                    if (wave == 0) track(yr[0]), track(yr[1]);
                                 }
                             }
                         }
@@ -536,31 +618,63 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
             }
         });
     }
-    // add this workgroup's partial dW^T to the global buffer (256 contiguous bytes per register)
+    if (ntile <= 0) return;  // the whole workgroup: its slice is empty and the sum skips it
+    // store this workgroup's partial dW^T as its own tiles (256 contiguous bytes per register);
+    // every tile of the job is written in full by exactly one wave
+    float* const mine = a.slabs + ((size_t)(jb.slab0 + slice * jb.n_acc) * 16) * 64 + lane;
     auto flush = [&](int tile, const f32x16& v) {
-        float* dst = a.gperm + ((size_t)tile * 16) * 64 + lane;
+        float* dst = mine + ((size_t)tile * 16) * 64;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(dst + r * 64, v[r]);
+        for (int r = 0; r < 16; ++r) dst[r * 64] = v[r];
     };
     // a bias gradient goes where the product with a ones column would have put it: column 0 of
-    // the tile, output row r = lane & 31 -> register (r & 3) + 4 (r >> 3) of lane 32 ((r >> 2) & 1)
+    // the tile, output row r -> register (r & 3) + 4 (r >> 3) of lane 32 ((r >> 2) & 1); the sum of
+    // row r is split over lanes r and r + 32; the rest of the tile is zero
     auto flush_bias = [&](int tile, float v) {
-        const int r = lane & 31;
-        atomicAdd(a.gperm + ((size_t)tile * 16 + (r & 3) + 4 * (r >> 3)) * 64 + 32 * ((r >> 2) & 1), v);
+        f32x16 t = zero16;
+        static_for<0, 16>([&](auto rc) {
+            constexpr int reg = decltype(rc)::value;
+            static_for<0, 2>([&](auto hc) {
+                constexpr int hsel = decltype(hc)::value, r = (reg & 3) + 4 * hsel + 8 * (reg >> 2);
+                const float sum = read_lane(v, r) + read_lane(v, r + 32);
+                if (lane == 32 * hsel) t[reg] = sum;
+            });
+        });
+        flush(tile, t);
     };
-    if (ntile <= 0) return;
     if constexpr (ROW) {
-        if (wave < NX) flush(jb.tile0 + wave, acc[0]);
-        if (BIAS && wave == 0) flush_bias(jb.tile0 + NX, bsum);
+        if (wave < NX) flush(wave, acc[0]);
+        if (BIAS && wave == 0) flush_bias(NX, bsum);
     } else {
         if (wave < jb.n_out) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) flush(jb.tile0 + wave * NI + i, acc[i]);
-            if constexpr (BIAS) flush_bias(jb.tile0 + wave * NI + NX, bsum);
+            for (int i = 0; i < NX; ++i) flush(wave * NI + i, acc[i]);
+            if constexpr (BIAS) flush_bias(wave * NI + NX, bsum);
         }
         if constexpr (NY1) {
-            if (wave < NX) flush(jb.tile0 + jb.n_out * NI + wave, accr);
-            if (BIAS && wave == 0) flush_bias(jb.tile0 + jb.n_out * NI + NX, bsum_r);
+            if (wave < NX) flush(jb.n_out * NI + wave, accr);
+            if (BIAS && wave == 0) flush_bias(jb.n_out * NI + NX, bsum_r);
+        }
+    }
+    // the workgroup's largest gradient pattern -> one atomic per workgroup (LDS is free: every
+    // wave is past its last stage once it has passed the first barrier)
+    {
+        unsigned m = ymax & 0xffffu, hi = ymax >> 16;
+        m = m > hi ? m : hi;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)m, off);
+            m = m > o ? m : o;
+        }
+        unsigned* slot = (unsigned*)lds;
+        __syncthreads();
+        if (lane == 0) slot[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned all = 0u;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) all = all > slot[w] ? all : slot[w];
+            if (all) atomicMax(a.status + ST_YMAX, all);
         }
     }
 }
@@ -598,6 +712,34 @@ __global__ __launch_bounds__(512) void mlp_dw_kernel(DwArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 2b. sum of the workgroups' partial tiles, in workgroup order
+// ---------------------------------------------------------------------------------------------
+struct ReduceArgs {
+    const float* slabs;
+    float* gperm;            // [tiles][16 regs][64 lanes]
+    int tile0[kNumJobs + 1]; // first summed tile of each job; [kNumJobs] = total
+    int n_acc[kNumJobs], slab0[kNumJobs], used[kNumJobs];
+};
+
+// One workgroup per summed tile, one float4 per thread.
+__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(ReduceArgs a) {
+    const int tile = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < kNumJobs; ++k)
+        if (tile >= a.tile0[k]) j = k;
+    const int local = tile - a.tile0[j], n_acc = a.n_acc[j], used = a.used[j];
+    const float4* src = (const float4*)(a.slabs + ((size_t)(a.slab0[j] + local) * 16) * 64) + threadIdx.x;
+    const size_t stride = (size_t)n_acc * 16 * 64 / 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < used; ++w) {
+        const float4 v = src[(size_t)w * stride];
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    ((float4*)(a.gperm + (size_t)tile * 16 * 64))[threadIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3. unpack
 // ---------------------------------------------------------------------------------------------
 struct GradPtrs {
@@ -607,7 +749,8 @@ struct GradPtrs {
 struct UnpackArgs {
     const float* gperm;
     GradPtrs out;
-    float inv_scale;
+    float gscale;      // > 0: the caller's factor; otherwise the one formed from status[ST_ABSMAX]
+    unsigned* status;
     int accumulate;
     int tile0[kNumProducts];  // per product (0..7 point layers, 8 bottleneck, 9 view, 10 rgb, 11 alpha):
     int n_in[kNumProducts];   // first accumulator tile, and input tiles per output tile (bias tile last)
@@ -653,6 +796,19 @@ __device__ __forceinline__ void view_slot(int f, int& tile, int& row) {
 // order), e = flat index inside it.
 __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned absmax = a.status[ST_ABSMAX], ymax = a.status[ST_YMAX];
+    const float gs = a.gscale > 0.f ? a.gscale : auto_gscale(absmax);
+    // saturated (the chain clamps at the largest finite fp16, 0x7bff), infinite or NaN; or, with a
+    // non-zero d raw, not one stored gradient as large as the smallest normal fp16 (0x0400)
+    unsigned flags = 0u;
+    if (ymax >= 0x7bffu || absmax >= 0x7f800000u) flags |= NERF_GRAD_SATURATED;
+    if (absmax != 0u && ymax < 0x0400u) flags |= NERF_GRAD_UNDERFLOW;
+    if (gi == 0) {
+        a.status[ST_FLAGS] = flags;
+        a.status[ST_GSCALE] = __builtin_bit_cast(unsigned, gs);
+        a.status[ST_ABSMAX_OUT] = absmax;
+        a.status[ST_YMAX_OUT] = ymax;
+    }
     if (gi >= a.first[24]) return;
     int pi = 0;
 #pragma unroll
@@ -676,7 +832,8 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
     const int job = layer;
     const int n_in = a.n_in[job];
     const int reg = (orow & 3) + 4 * (orow >> 3), lane = 32 * ((orow >> 2) & 1) + irow;
-    const float v = a.gperm[((size_t)(a.tile0[job] + ot * n_in + it) * 16 + reg) * 64 + lane] * a.inv_scale;
+    float v = a.gperm[((size_t)(a.tile0[job] + ot * n_in + it) * 16 + reg) * 64 + lane] * (1.0f / gs);
+    if (flags) v = __builtin_nanf("");
     float* dst = a.out.g[pi] + e;
     *dst = a.accumulate ? *dst + v : v;
 }
@@ -684,11 +841,12 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
 // The jobs of one network, their accumulator tiles in the partial-sum buffer and their share of
 // `total_wgs` workgroups (in proportion to the 1 KiB loads a job issues per wave tile).  prod_tile0 / prod_n_in tell
 // the unpack kernel where each layer's product lives.
-static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs, int* prod_tile0 = nullptr, int* prod_n_in = nullptr) {
+static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs, int* prod_tile0 = nullptr, int* prod_n_in = nullptr,
+                      int* slab_tiles = nullptr) {
     int blocks[kNumJobs], n_acc[kNumJobs], layer_of[kNumJobs];
     int nj = 0;
     auto add = [&](int layer, int kind, int x0, int x1, int yb, int y1b, int yk, int n_out, int n_in, int row_tiles, int nloads) {
-        jb[nj] = DwJob{kind, x0, x1, yb, y1b, yk, n_out, 0, 0, 0};
+        jb[nj] = DwJob{kind, x0, x1, yb, y1b, yk, n_out, 0, 0, 0, 0, 0, 0};
         blocks[nj] = nloads, n_acc[nj] = n_in * n_out + row_tiles, layer_of[nj] = layer;
         if (prod_n_in) prod_n_in[layer] = n_in;
         ++nj;
@@ -704,6 +862,7 @@ static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs, int* prod_tile
     int tiles = 0, bytes = 0;
     for (int j = 0; j < nj; ++j) {
         jb[j].tile0 = tiles;
+        jb[j].n_acc = n_acc[j];
         if (prod_tile0) prod_tile0[layer_of[j]] = tiles;
         tiles += n_acc[j];
         bytes += blocks[j];
@@ -729,18 +888,31 @@ static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs, int* prod_tile
             if (frac[j] > frac[best]) best = j;
         jb[best].wgs += 1, frac[best] -= 1.0, given += 1;
     }
-    int wg = 0;
+    int wg = 0, slab = 0;
     for (int j = 0; j < nj; ++j) {
         jb[j].wg0 = wg;
+        jb[j].slab0 = slab;
         wg += jb[j].wgs;
+        slab += jb[j].wgs * jb[j].n_acc;
     }
+    if (slab_tiles) *slab_tiles = slab;
 }
 
-static int gperm_tiles() {
+// Workgroups of the weight-gradient kernel: one per CU, fewer when there are few wave tiles.
+static int dw_workgroups(int64_t wave_tiles, int cus) {
+    if (wave_tiles >= (int64_t)cus * 4) return cus;
+    const int64_t n = wave_tiles / 4;
+    return (int)(n > kNumJobs ? n : kNumJobs);
+}
+
+constexpr size_t kTileFloats = 16 * 64;
+
+// Layout of `partial`: status block, summed tiles, then the per-workgroup partial tiles.
+static size_t partial_bytes_for(int wgs) {
     DwJob jb[kNumJobs];
-    int tiles;
-    make_jobs(jb, &tiles, 256);
-    return tiles;
+    int tiles, slab;
+    make_jobs(jb, &tiles, wgs, nullptr, nullptr, &slab);
+    return kStatusBytes + ((size_t)tiles + slab) * kTileFloats * sizeof(float);
 }
 
 }  // namespace nerf
@@ -771,34 +943,65 @@ NERF_API size_t nerf_mlp_grad_bytes(int64_t n_points) {
     return (size_t)wave_tiles * layout::kGradBlocks * layout::kFragBytes;
 }
 
-NERF_API size_t nerf_mlp_partial_bytes(void) { return (size_t)gperm_tiles() * 16 * 64 * sizeof(float); }
+NERF_API size_t nerf_mlp_partial_bytes(void) {
+    // sized for one workgroup per CU of the current device (256 when there is none to ask)
+    int cus = device_cu_count();
+    if (cus < 256) cus = 256;
+    return partial_bytes_for(cus);
+}
 
 NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const float* d_raw,
                                int64_t n_points, float gscale, void* gbuf, void* partial,
                                float* const* grads, int accumulate, nerf_stream_t stream) {
     NERF_REQUIRE(packed_bwd && act && d_raw && gbuf && partial && grads, "nerf_mlp_backward: null pointer");
-    NERF_REQUIRE(n_points >= 0 && gscale > 0.f, "nerf_mlp_backward: bad size or scale");
+    NERF_REQUIRE(n_points >= 0, "nerf_mlp_backward: bad size");
+    NERF_REQUIRE(gscale == gscale && gscale < 3.0e38f, "nerf_mlp_backward: gscale must be finite (<= 0 selects the automatic scale)");
     NERF_REQUIRE((((uintptr_t)packed_bwd | (uintptr_t)act | (uintptr_t)d_raw | (uintptr_t)gbuf | (uintptr_t)partial) & 15) == 0,
                  "nerf_mlp_backward: buffers must be 16-byte aligned");
+    UnpackArgs ua{};
+    for (int i = 0; i < 24; ++i) {
+        NERF_REQUIRE(grads[i], "nerf_mlp_backward: grads[%d] is null", i);
+        ua.out.g[i] = grads[i];
+    }
     if (n_points == 0) return 0;
     hipStream_t st = as_stream(stream);
     const int64_t blocks = (n_points + kPointsPerBlock - 1) / kPointsPerBlock;
     if (blocks > 0x7fffffffLL) return NERF_FAIL(NERF_E_UNSUPPORTED, "nerf_mlp_backward: too many points");
-    ChainArgs ca{(const char*)packed_bwd, (const char*)act, (const float4*)d_raw, (char*)gbuf, n_points, gscale};
+    int cus = device_cu_count();
+    if (cus <= 0) return NERF_FAIL(NERF_E_UNSUPPORTED, "nerf_mlp_backward: no current device");
+
+    unsigned* status = (unsigned*)partial;
+    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, st);
+    if (e != hipSuccess) return NERF_FAIL((int)e, "nerf_mlp_backward(memset): %s", hipGetErrorString(e));
+    {
+        const int64_t want = (n_points + 255) / 256;
+        draw_absmax_kernel<<<(unsigned)(want < 2048 ? want : 2048), 256, 0, st>>>((const float4*)d_raw, n_points, status);
+        int rc = check_launch("nerf_mlp_backward(absmax)");
+        if (rc) return rc;
+    }
+    ChainArgs ca{(const char*)packed_bwd, (const char*)act, (const float4*)d_raw, (char*)gbuf, n_points,
+                 gscale > 0.f ? gscale : 0.f, status};
     mlp_bwd_chain_kernel<<<(unsigned)blocks, 512, 0, st>>>(ca);
     int rc = check_launch("nerf_mlp_backward(chain)");
     if (rc) return rc;
 
     DwArgs da{};
-    da.act = (const char*)act, da.gbuf = (const char*)gbuf, da.gperm = (float*)partial;
+    da.act = (const char*)act, da.gbuf = (const char*)gbuf, da.status = status;
     da.wave_tiles = blocks * kWavesPerBlock;
-    int tiles;
-    int wgs = 256;
-    if (da.wave_tiles < 256 * 4) wgs = (int)(da.wave_tiles / 4 > kNumJobs ? da.wave_tiles / 4 : kNumJobs);
-    UnpackArgs ua{};
-    make_jobs(da.job, &tiles, wgs, ua.tile0, ua.n_in);
-    hipError_t e = hipMemsetAsync(partial, 0, (size_t)tiles * 16 * 64 * sizeof(float), st);
-    if (e != hipSuccess) return NERF_FAIL((int)e, "nerf_mlp_backward(memset): %s", hipGetErrorString(e));
+    int tiles, slab_tiles;
+    const int wgs = dw_workgroups(da.wave_tiles, cus);
+    make_jobs(da.job, &tiles, wgs, ua.tile0, ua.n_in, &slab_tiles);
+    float* gperm = (float*)((char*)partial + kStatusBytes);
+    da.slabs = gperm + (size_t)tiles * kTileFloats;
+    ReduceArgs ra{};
+    ra.slabs = da.slabs, ra.gperm = gperm;
+    for (int j = 0; j < kNumJobs; ++j) {
+        DwJob& jb = da.job[j];
+        const int64_t per = (da.wave_tiles + jb.wgs - 1) / jb.wgs;
+        jb.used = (int)((da.wave_tiles + per - 1) / per);
+        ra.tile0[j] = jb.tile0, ra.n_acc[j] = jb.n_acc, ra.slab0[j] = jb.slab0, ra.used[j] = jb.used;
+    }
+    ra.tile0[kNumJobs] = tiles;
     const int total_wgs = da.job[kNumJobs - 1].wg0 + da.job[kNumJobs - 1].wgs;
 #ifdef DW_STAMPS
     da.stamps = g_dw_stamps;
@@ -806,14 +1009,13 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     mlp_dw_kernel<<<total_wgs, 512, 0, st>>>(da);
     rc = check_launch("nerf_mlp_backward(dw)");
     if (rc) return rc;
+    mlp_dw_reduce_kernel<<<tiles, 256, 0, st>>>(ra);
+    rc = check_launch("nerf_mlp_backward(reduce)");
+    if (rc) return rc;
 
-    ua.gperm = (const float*)partial, ua.inv_scale = 1.0f / gscale, ua.accumulate = accumulate;
+    ua.gperm = gperm, ua.gscale = gscale > 0.f ? gscale : 0.f, ua.status = status, ua.accumulate = accumulate;
     static const int dims[12][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
                                     {256, 256}, {256, 256}, {256, 256}, {283, 128}, {128, 3}, {256, 1}};
-    for (int i = 0; i < 24; ++i) {
-        NERF_REQUIRE(grads[i], "nerf_mlp_backward: grads[%d] is null", i);
-        ua.out.g[i] = grads[i];
-    }
     ua.first[0] = 0;
     for (int i = 0; i < 24; ++i) {
         const int in_dim = dims[i >> 1][0], out_dim = dims[i >> 1][1];
@@ -821,4 +1023,18 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     }
     mlp_grad_unpack_kernel<<<(ua.first[24] + 255) / 256, 256, 0, st>>>(ua);
     return check_launch("nerf_mlp_backward(unpack)");
+}
+
+NERF_API int nerf_mlp_backward_status(const void* partial, int* flags, float* gscale_used, float* absmax_d_raw,
+                                      nerf_stream_t stream) {
+    NERF_REQUIRE(partial && flags, "nerf_mlp_backward_status: null pointer");
+    unsigned host[8] = {};
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemcpyAsync(host, partial, sizeof host, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return NERF_FAIL((int)e, "nerf_mlp_backward_status: %s", hipGetErrorString(e));
+    *flags = (int)host[ST_FLAGS];
+    if (gscale_used) memcpy(gscale_used, &host[ST_GSCALE], sizeof(float));
+    if (absmax_d_raw) memcpy(absmax_d_raw, &host[ST_ABSMAX_OUT], sizeof(float));
+    return 0;
 }

@@ -55,12 +55,14 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0., white_bkgd=False, noise=N
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False,
                 perturb=0., N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.,
-                verbose=False, perturb_u=None, pdf_u=None, **fork_kwargs):
+                verbose=False, perturb_u=None, pdf_u=None, noise0=None, noise1=None, **fork_kwargs):
     """Volumetric rendering of a ray batch [N, 11] = (o, d, near, far, viewdir).
 
     Returns a dict with rgb_map [N,3], disp_map, acc_map, depth_map [N]; with N_importance > 0 also
     rgb0, disp0, acc0, z_std; with retraw the last network output raw [N,S,4].
-    `perturb_u` / `pdf_u` let a caller supply the uniforms otherwise drawn with torch.rand.
+    `perturb_u` / `pdf_u` let a caller supply the uniforms otherwise drawn with torch.rand, and
+    `noise0` / `noise1` ([N,Sc] / [N,Sc+Si]) the standard normals that raw_noise_std scales in the
+    coarse / fine compositing (otherwise drawn with torch.randn).
     Fork-only keyword arguments (choose_keypoint_closest_depth, ...) are accepted and ignored.
     """
     rays = nv.f32(ray_batch)
@@ -80,10 +82,15 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
         return nv.f32(network_query_fn(pts, rays[:, 8:11], net), rays.device)
 
-    def composite(raw, z):
-        noise = None
+    def composite(raw, z, noise):
         if raw_noise_std > 0.:
-            noise = torch.randn(z.shape, dtype=torch.float32, device=rays.device)
+            if noise is None:
+                noise = torch.randn(z.shape, dtype=torch.float32, device=rays.device)
+            noise = nv.f32(noise, rays.device)
+            if tuple(noise.shape) != tuple(z.shape):
+                raise ValueError(f"render_rays: noise must be {tuple(z.shape)}, got {tuple(noise.shape)}")
+        else:
+            noise = None
         if rec:
             return training.Composite.apply(raw, z, rays, bool(white_bkgd), noise, float(raw_noise_std))
         return ops.composite_fwd(raw, z, rays[:, 3:6], width, white_bkgd, noise, raw_noise_std)
@@ -92,14 +99,14 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         perturb_u = torch.rand((n, N_samples), dtype=torch.float32, device=rays.device)
     z_vals = ops.sample_z(rays, N_samples, lindisp, perturb_u if perturb > 0. else None)
     raw = query(z_vals, network_fn)
-    rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals)
+    rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals, noise0)
     ret = {}
     if N_importance > 0:
         ret.update(rgb0=rgb_map, disp0=disp_map, acc0=acc_map)
         z_vals, _, z_std = ops.resample_merge(z_vals, weights.detach(), N_importance, det=(perturb == 0.),
                                               u=pdf_u, want_samples=False)
         raw = query(z_vals, network_fine if network_fine is not None else network_fn)
-        rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals)
+        rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals, noise1)
         ret['z_std'] = z_std
     ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map, depth_map=depth_map)
     if retraw:

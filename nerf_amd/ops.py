@@ -325,9 +325,23 @@ def partial_bytes():
     return int(nv.lib().nerf_mlp_partial_bytes())
 
 
+GRAD_SATURATED, GRAD_UNDERFLOW = 1, 2
+
+
+def mlp_backward_status(partial):
+    """(flags, gscale_used, max|d_raw|) of the last mlp_backward that used `partial`; waits for it."""
+    flags, gs, mx = ctypes.c_int(0), ctypes.c_float(0.), ctypes.c_float(0.)
+    with torch.cuda.device(partial.device):
+        nv.check(nv.lib().nerf_mlp_backward_status(nv.ptr(partial), ctypes.byref(flags), ctypes.byref(gs),
+                                                   ctypes.byref(mx), nv.stream()), "nerf_mlp_backward_status")
+    return flags.value, gs.value, mx.value
+
+
 def mlp_backward(packed_bwd, act, d_raw, gscale, gbuf, partial, grads, accumulate=False):
     """Parameter gradients (24 tensors shaped like the parameters, written in place) from
-    d_raw [N,S,4] and the activations saved by mlp_forward_train."""
+    d_raw [N,S,4] and the activations saved by mlp_forward_train.  gscale None or <= 0: the
+    fp16 gradient scale is formed on the device from max|d_raw|."""
+    gscale = 0.0 if gscale is None else gscale
     n_points = d_raw.numel() // 4
     if gbuf.numel() < grad_bytes(n_points) or partial.numel() < partial_bytes():
         raise ValueError("mlp_backward: scratch too small")

@@ -19,7 +19,7 @@ from .run_nerf_helpers import get_embedder, get_rays, init_nerf_model, to8b
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """run_nerf.py:15-25: render rays in `chunk`-sized pieces and concatenate every returned key."""
     all_ret = defaultdict(list)
-    per_ray = ('perturb_u', 'pdf_u')
+    per_ray = ('perturb_u', 'pdf_u', 'noise0', 'noise1')
     for i in range(0, rays_flat.shape[0], chunk):
         kw = {k: (v[i:i + chunk] if (k in per_ray and v is not None) else v) for k, v in kwargs.items()}
         ret = nerf_renderer.render_rays(rays_flat[i:i + chunk], **kw)

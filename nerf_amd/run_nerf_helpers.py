@@ -128,7 +128,10 @@ class NerfModel:
         self._packed_version = None
         self._packed_bwd_version = None
         self._epoch = 0          # bumped by updates that bypass torch (the fused Adam kernel)
-        self.grad_scale = 65536.0  # factor applied to d_raw before the fp16 gradient chain
+        # factor applied to d_raw before the fp16 gradient chain; None = formed on the device from
+        # max|d_raw| at every backward pass (what callers should leave it at)
+        self.grad_scale = None
+        self._grad_partial = None  # scratch of the last backward pass; its head is the status block
         _MODELS_BY_STORAGE[self.flat.data_ptr()] = self
 
     # Keras-like surface
@@ -176,6 +179,14 @@ class NerfModel:
                 ops.mlp_pack_bwd([p.detach() for p in self.params], self._packed_bwd)
             self._packed_bwd_version = ver
         return self._packed_bwd
+
+    def grad_status(self):
+        """(flags, gscale_used, max|d_raw|) of this network's last backward pass; flags is a
+        combination of ops.GRAD_SATURATED / ops.GRAD_UNDERFLOW (0 = the gradients are sound).
+        Waits for the GPU, so call it where a synchronisation is acceptable (e.g. when printing)."""
+        if self._grad_partial is None:
+            return 0, 0.0, 0.0
+        return ops.mlp_backward_status(self._grad_partial)
 
     def mark_dirty(self):
         """Call after writing the parameters behind torch's back (raw kernels on self.flat)."""

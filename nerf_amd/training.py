@@ -77,7 +77,9 @@ class MLPQuery(torch.autograd.Function):
         n_points = d_raw.numel() // 4
         dev = d_raw.device
         gbuf = torch.empty((ops.grad_bytes(n_points),), dtype=torch.uint8, device=dev)
-        partial = torch.empty((ops.partial_bytes(),), dtype=torch.uint8, device=dev)
+        partial = model._grad_partial
+        if partial is None or partial.device != dev or partial.numel() < ops.partial_bytes():
+            partial = model._grad_partial = torch.empty((ops.partial_bytes(),), dtype=torch.uint8, device=dev)
         flat = torch.empty_like(model.flat)
         grads, at = [], 0
         for p in model.params:

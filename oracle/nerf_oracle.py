@@ -334,6 +334,11 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     """run_nerf.py:28-119.  Returns [rgb_map, disp_map, acc_map, extras]."""
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, focal, c2w, dtype)                      # :63
+    elif len(rays) == 3:                                                         # :66-69
+        rays_o, rays_d = np.asarray(rays[0], dtype=dtype), np.asarray(rays[1], dtype=dtype)
+        depth = np.asarray(rays[2], dtype=dtype).reshape(-1)
+        far = depth[:, None] * dtype(1.1)
+        near = depth[:, None] * dtype(0.9)
     else:
         rays_o, rays_d = np.asarray(rays[0], dtype=dtype), np.asarray(rays[1], dtype=dtype)  # :71
     kwargs.pop('K', None)                                                        # :75-77
@@ -349,8 +354,8 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d, dtype)        # :94-95
     rays_o = rays_o.reshape(-1, 3).astype(dtype)
     rays_d = rays_d.reshape(-1, 3).astype(dtype)
-    near_a = dtype(near) * np.ones_like(rays_d[..., :1])                         # :100-102
-    far_a = dtype(far) * np.ones_like(rays_d[..., :1])
+    near_a = np.asarray(near, dtype=dtype) * np.ones_like(rays_d[..., :1])       # :100-102
+    far_a = np.asarray(far, dtype=dtype) * np.ones_like(rays_d[..., :1])
     rb = np.concatenate([rays_o, rays_d, near_a, far_a], -1)                     # :105
     if use_viewdirs:
         rb = np.concatenate([rb, viewdirs], -1)                                  # :108

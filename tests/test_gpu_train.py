@@ -182,6 +182,13 @@ def test_mlp_backward(gpu, n, S):
         rel = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
         assert rel < 5e-3, (name, rel)
         assert np.max(np.abs(g - r)) < 2e-2 * np.max(np.abs(r)) + 1e-12, name
+    # the automatic scale gives the same answer to rounding
+    auto = [torch.zeros_like(p) for p in m.params]
+    ops.mlp_backward(pb, act, _t(d_raw, gpu), None, gbuf, part, auto)
+    assert ops.mlp_backward_status(part)[0] == 0
+    for name, g, r in zip(names, auto, ref):
+        rel = np.linalg.norm(g.cpu().numpy() - r) / max(np.linalg.norm(r), 1e-30)
+        assert rel < 5e-3, (name, rel)
     # accumulate mode adds on top
     grads2 = [g.clone() for g in grads]
     ops.mlp_backward(pb, act, _t(d_raw, gpu), 4096.0, gbuf, part, grads2, accumulate=True)
@@ -257,10 +264,12 @@ def test_mse_and_keras_adam(gpu):
     np.testing.assert_allclose(flat.cpu().numpy(), th, rtol=2e-6, atol=2e-7)
 
 
-def test_training_step_gradients_end_to_end(gpu):
+@pytest.mark.parametrize("n", [96, 4096])
+def test_training_step_gradients_end_to_end(gpu, n):
     """tape.gradient over render() (64+128 samples, perturb and random resampling uniforms shared
-    with the reference) against torch-CPU autograd of the restatement in float64."""
-    from nerf_amd import training
+    with the reference) against torch autograd of the restatement in float64, at a small batch and
+    at the reference's default N_rand.  The fp16 gradient scale is left to the library."""
+    from nerf_amd import ops, training
     from nerf_amd.run_nerf import create_nerf, render
     from nerf_amd.run_nerf_helpers import img2mse
     from tests.util import default_args
@@ -270,37 +279,129 @@ def test_training_step_gradients_end_to_end(gpu):
     wc, wf = trained_like_weights(rng), trained_like_weights(rng)
     models['model'].set_weights(wc)
     models['model_fine'].set_weights(wf)
-    n = 96
+    assert models['model'].grad_scale is None and models['model_fine'].grad_scale is None
     rb = synthetic_rays(n, seed=8)
     target = rng.uniform(size=(n, 3)).astype(np.float32)
     pu = rng.uniform(size=(n, 64)).astype(np.float32)
     uu = rng.uniform(size=(n, 128)).astype(np.float32)
-    for m in models.values():
-        m.grad_scale = 48.0 * n * 16
     with training.GradientTape() as tape:
-        rgb, disp, acc, extras = render(1, 1, 1., chunk=1024, rays=(_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)),
+        rgb, disp, acc, extras = render(1, 1, 1., chunk=1024 * 32, rays=(_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)),
                                         near=2., far=6., retraw=True, perturb_u=_t(pu, gpu), pdf_u=_t(uu, gpu),
                                         **kw_train)
         loss = img2mse(rgb, _t(target, gpu)) + img2mse(extras['rgb0'], _t(target, gpu))
     grads = tape.gradient(loss, grad_vars)
     assert len(grads) == 48
-    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    for m in models.values():
+        flags, gs, mx = m.grad_status()
+        assert flags == 0 and mx > 0
+        assert 1024. <= gs * mx < 2048. and np.log2(gs) == round(np.log2(gs))   # a power of two, on target
+    # float64 autograd of the restatement, on the GPU, a slice of rays at a time
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=gpu)
     Wc = [t64(w).requires_grad_(True) for w in wc]
     Wf = [t64(w).requires_grad_(True) for w in wf]
-    out = trs.render_rays(t64(rb), Wc, Wf, white_bkgd=True, perturb_u=t64(pu), pdf_u=t64(uu))
-    ref_loss = trs.loss_fn(out, t64(target))
-    ref_loss.backward()
-    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=2e-3)
-    ref = [w.grad.numpy() for w in Wc + Wf]
+    ref_loss = 0.
+    for i in range(0, n, 512):
+        sl = slice(i, i + 512)
+        out = trs.render_rays(t64(rb[sl]), Wc, Wf, white_bkgd=True, perturb_u=t64(pu[sl]), pdf_u=t64(uu[sl]))
+        tt = t64(target[sl])
+        part = (((out['rgb_map'] - tt) ** 2).sum() + ((out['rgb0'] - tt) ** 2).sum()) / (n * 3)
+        part.backward()
+        ref_loss += float(part)
+    np.testing.assert_allclose(float(loss), ref_loss, rtol=2e-3)
+    ref = [w.grad.cpu().numpy() for w in Wc + Wf]
     got = [g.cpu().numpy().astype(np.float64) for g in grads]
     # whole-gradient agreement per network (ReLU units and resampling bins that flip between the
     # fp16 and the fp64 forward move individual entries, not the direction)
     for lo, hi, name in [(0, 24, 'coarse'), (24, 48, 'fine')]:
         a = np.concatenate([g.ravel() for g in got[lo:hi]])
         b = np.concatenate([g.ravel() for g in ref[lo:hi]])
+        assert np.all(np.isfinite(a)), name
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
         rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
         assert cos > 0.999 and rel < 5e-2, (name, cos, rel)
+
+
+def _backward_setup(gpu, n, S, seed, d_raw_scale=1e-4):
+    from nerf_amd import ops
+    from nerf_amd.run_nerf_helpers import init_nerf_model
+    rng = np.random.default_rng(seed)
+    ws = trained_like_weights(rng)
+    m = init_nerf_model(8, 256, 63, 27, 4, [4], True, device=gpu)
+    m.set_weights(ws)
+    rb = synthetic_rays(n, seed=seed)
+    rays = _t(rb, gpu)
+    z = ops.sample_z(rays, S)
+    d_raw = _t((rng.normal(size=(n, S, 4)) * d_raw_scale).astype(np.float32), gpu)
+    act = torch.zeros((ops.act_bytes(n * S),), dtype=torch.uint8, device=gpu)
+    ops.mlp_forward_train(m.packed(), rays, z, act)
+    gbuf = torch.empty((ops.grad_bytes(n * S),), dtype=torch.uint8, device=gpu)
+    part = torch.empty((ops.partial_bytes(),), dtype=torch.uint8, device=gpu)
+    return m, ws, rb, z, d_raw, act, gbuf, part
+
+
+@pytest.mark.parametrize("n,S", [(40, 64), (700, 192)])
+def test_mlp_backward_same_inputs_same_bits(gpu, n, S):
+    """The weight gradients are summed in a fixed order: two calls on the same inputs agree bit
+    for bit (few wave tiles: fewer workgroups than CUs; many: one per CU, several tiles each),
+    whatever the scratch buffers held before."""
+    from nerf_amd import ops
+    m, ws, rb, z, d_raw, act, gbuf, part = _backward_setup(gpu, n, S, 5)
+    runs = []
+    for fill in (0, 255):
+        gbuf.fill_(fill)
+        part.fill_(fill)
+        grads = [torch.full_like(p, float('nan')) for p in m.params]
+        ops.mlp_backward(m.packed_bwd(), act, d_raw, None, gbuf, part, grads)
+        assert ops.mlp_backward_status(part)[0] == 0
+        runs.append(grads)
+    for a, b in zip(*runs):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+def test_gradient_scale_is_automatic_and_misuse_is_reported(gpu):
+    """gscale <= 0 forms the factor on the device; an explicit factor is used as given and a
+    grossly wrong one is reported (status bits, NaN gradients) instead of being silently used."""
+    from nerf_amd import ops
+    n, S = 8, 64
+    m, ws, rb, z, d_raw, act, gbuf, part = _backward_setup(gpu, n, S, 108)
+    pb = m.packed_bwd()
+    ref, flip_rate = _mlp_grads_reference(ws, rb, z.cpu().numpy(), d_raw.cpu().numpy(), act)
+
+    def run(gscale):
+        grads = [torch.zeros_like(p) for p in m.params]
+        ops.mlp_backward(pb, act, d_raw, gscale, gbuf, part, grads)
+        return grads, ops.mlp_backward_status(part)
+
+    def worst_rel(grads):
+        return max(np.linalg.norm(g.cpu().numpy() - r) / max(np.linalg.norm(r), 1e-30) for g, r in zip(grads, ref))
+
+    grads, (flags, gs, mx) = run(None)
+    assert flags == 0 and abs(mx - float(d_raw.abs().max())) < 1e-12 and 1024. <= gs * mx < 2048.
+    assert worst_rel(grads) < 5e-3
+    # an explicit factor equal to the automatic one gives the same bits
+    again, (flags2, gs2, _) = run(gs)
+    assert flags2 == 0 and gs2 == gs and all(torch.equal(a, b) for a, b in zip(grads, again))
+    # 2^10 too high: the first conversions already saturate -> reported, gradients are NaN
+    high, (fh, _, _) = run(gs * 1024.)
+    assert fh & ops.GRAD_SATURATED
+    assert all(bool(torch.isnan(g).all()) for g in high)
+    # 2^10 too low is still inside the fp16 range (scaled d_raw around 1): sound, and not flagged
+    low, (fl, _, _) = run(gs / 1024.)
+    assert fl == 0 and worst_rel(low) < 5e-3
+    # 2^30 too low: nothing but denormals and zeros reach the weight gradients -> reported
+    lost, (fu, _, _) = run(gs / 2. ** 30)
+    assert fu & ops.GRAD_UNDERFLOW
+    assert all(bool(torch.isnan(g).all()) for g in lost)
+    # a NaN in d_raw is reported, not averaged away
+    bad = d_raw.clone()
+    bad[3, 7, 1] = float('nan')
+    grads_nan = [torch.zeros_like(p) for p in m.params]
+    ops.mlp_backward(pb, act, bad, None, gbuf, part, grads_nan)
+    assert ops.mlp_backward_status(part)[0] & ops.GRAD_SATURATED
+    # all-zero d_raw: zero gradients, nothing to report
+    zero = [torch.ones_like(p) for p in m.params]
+    ops.mlp_backward(pb, act, torch.zeros_like(d_raw), None, gbuf, part, zero)
+    assert ops.mlp_backward_status(part)[0] == 0 and all(float(g.abs().max()) == 0. for g in zero)
 
 
 def test_training_reduces_loss(gpu):
@@ -315,8 +416,6 @@ def test_training_reduces_loss(gpu):
     rb = synthetic_rays(n, seed=3)
     rays = (_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu))
     target = _t(np.random.default_rng(1).uniform(0.2, 0.8, size=(n, 3)), gpu)
-    for m in models.values():
-        m.grad_scale = 48.0 * n * 16
     opt = training.Adam(training.ExponentialDecay(5e-4, 250 * 1000, 0.1))
     fn = lambda r: render(1, 1, 1., chunk=1024 * 32, rays=r, near=2., far=6., retraw=True, **kw_train)
     losses = []
