@@ -185,7 +185,7 @@ size_t nerf_mlp_partial_bytes(void);
  * order, each shaped like its parameter.  `act` is what nerf_mlp_forward_train saved for the same
  * points.  The chain runs in fp16 with fp32 accumulation; d_raw is multiplied by a power of two
  * first and the result divided by it.  gscale <= 0 (the normal use): the factor is formed on the
- * device from max|d_raw| so that the largest scaled element lies in [1024, 2048) -- no host
+ * device from max|d_raw| so that the largest scaled element lies in [256, 512) -- no host
  * synchronisation.  gscale > 0: the caller's factor is used as given.  Either way the call records
  * whether a layer gradient saturated the fp16 range (or was not finite) or everything sank below
  * the smallest normal fp16; when either happened the gradients are written as NaN, never as

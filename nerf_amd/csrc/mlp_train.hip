@@ -25,7 +25,7 @@
 // The gradient scale.  The chain carries gradients in fp16, so d raw is multiplied by a power of
 // two on entry and the result divided by it on exit.  By default the factor is formed on the
 // device from max |d raw| (draw_absmax_kernel) so that the largest scaled element lies in
-// [1024, 2048): 32x of headroom to the fp16 maximum for growth inside the chain, 2^24 of range
+// [256, 512): 128x of headroom to the fp16 maximum for growth inside the chain, 2^22 of range
 // below it before the smallest normal number.  The weight-gradient kernel, which reads every stored
 // layer gradient anyway, records the largest fp16 bit pattern it saw; the unpack kernel turns that
 // into a status word (saturated / non-finite, or everything below the smallest normal number) and,
@@ -48,11 +48,11 @@ enum StatusWord {
     ST_YMAX_OUT = 7,    // out: copy of ST_YMAX
 };
 
-// The power of two that brings mx into [1024, 2048); 1 when mx is zero, denormal or not finite.
+// The power of two that brings mx into [256, 512); 1 when mx is zero, denormal or not finite.
 __host__ __device__ inline float auto_gscale(unsigned absmax_bits) {
     const int e = (int)((absmax_bits >> 23) & 0xffu);
     if (e == 0 || e == 255) return 1.0f;
-    int f = 127 + 10 - (e - 127);
+    int f = 127 + 8 - (e - 127);
     f = f < 1 ? 1 : f > 254 ? 254 : f;
     const unsigned bits = (unsigned)f << 23;
 #if defined(__HIP_DEVICE_COMPILE__)

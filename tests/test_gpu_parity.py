@@ -333,6 +333,38 @@ def test_mlp_forward_pts(gpu, n, S):
     _check_raw(raw, ref)
 
 
+@pytest.mark.parametrize("scale_hidden,alpha_scale,sigma_bias", [(1., 300., 50.), (2., 1., .5), (2., 30., 5.), (3., 1., .5)])
+def test_mlp_forward_away_from_glorot_scale(gpu, scale_hidden, alpha_scale, sigma_bias):
+    """Weights scaled up (activations grow by the factor per layer: x256 / x6561 by the last layer)
+    and a sharpened density head (|sigma| in the hundreds and beyond).  fp16 operands carry a
+    relative error, so the bound that holds at every scale is relative to the magnitude of the
+    channel: 4e-3 of max|rgb pre-activation| and of max|sigma|; the absolute 2e-3 on the colour
+    after the sigmoid holds while the pre-activations are of order one."""
+    from nerf_amd import ops
+    rng = np.random.default_rng(int(scale_hidden * 10 + alpha_scale))
+    ws = trained_like_weights(rng, scale_hidden=scale_hidden, alpha_scale=alpha_scale, sigma_bias=sigma_bias)
+    model = _model_from(ws, gpu)
+    n, S = 16, 64
+    pts = rng.uniform(-3., 3., size=(n, S, 3)).astype(np.float32)
+    vd = rng.normal(size=(n, 3))
+    vd = (vd / np.linalg.norm(vd, axis=-1, keepdims=True)).astype(np.float32)
+    raw = ops.mlp_forward_pts(model.packed(), _t(pts, gpu), _t(vd, gpu)).cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(raw))
+    ref = orc.run_network(pts, vd, ws, dtype=np.float64)
+    m_rgb, m_sig = float(np.max(np.abs(ref[..., :3]))), float(np.max(np.abs(ref[..., 3])))
+    e_pre = float(np.max(np.abs(raw[..., :3] - ref[..., :3])))
+    e_sig = float(np.max(np.abs(raw[..., 3] - ref[..., 3])))
+    sig = lambda v: 1. / (1. + np.exp(-v))
+    e_rgb = float(np.max(np.abs(sig(raw[..., :3]) - sig(ref[..., :3]))))
+    print(f"scale {scale_hidden} alpha x{alpha_scale}: max|rgb_pre| {m_rgb:.3g} max|sigma| {m_sig:.3g} "
+          f"err rgb_pre {e_pre:.3g} sigma {e_sig:.3g} sigmoid(rgb) {e_rgb:.3g}")
+    assert e_pre < 4e-3 * max(1., m_rgb) and e_sig < 4e-3 * max(1., m_sig)
+    if m_rgb < 4.:
+        assert e_rgb < RGB_TOL
+    if alpha_scale >= 30.:
+        assert m_sig > 100.
+
+
 def test_mlp_layer_wiring_by_zeroing_blocks(gpu):
     """Each structural choice of the network is observable: the skip concat order [pts, h], the
     linear bottleneck, the [bottleneck, views] order and the (rgb, alpha) output order."""
@@ -446,18 +478,26 @@ def test_mlp_hidden_activation_saturates_at_fp16_max(gpu):
 # ---------------------------------------------------------------------------------------------
 # end to end
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("white_bkgd,lindisp", [(True, False), (False, True)])
-def test_render_rays_end_to_end(gpu, white_bkgd, lindisp):
+@pytest.mark.parametrize("white_bkgd,lindisp,field", [(True, False, 'glorot'), (False, True, 'glorot'),
+                                                      (True, False, 'sharp')])
+def test_render_rays_end_to_end(gpu, white_bkgd, lindisp, field):
     """Whole path at 64+128 samples.  Two comparisons: (1) stage-wise -- the oracle re-runs the
     fine pass on the depths the GPU produced, so the only difference left is the fp16 MLP and
     fp32 compositing: max abs rgb error <= 2e-3; (2) free-running -- the oracle resamples for
     itself; resampling amplifies coarse-pass rounding in low-mass bins, so the bound there is on
-    image quality: PSNR against a common target moves by <= 0.05 dB."""
+    image quality: PSNR against a common target moves by <= 0.05 dB.
+
+    field 'sharp': a spectrally decaying field with the density head sharpened 300x (|sigma| up
+    to several hundred, the magnitude of a fitted scene).  The density's error is relative (about
+    1e-3 of max|sigma|), so where a sample sits on a surface (sigma between 0 and a few units,
+    next to hundreds) its alpha moves by percents: the stage-wise colour error is bounded at 2e-3
+    for 90 % of the rays and at 2e-2 for all, and the PSNR criterion holds unchanged."""
     from nerf_amd.run_nerf import create_nerf, render
     args = default_args(white_bkgd=white_bkgd, lindisp=lindisp)
     kw_train, kw_test, start, grad_vars, models = create_nerf(args)
     rng = np.random.default_rng(5)
-    wc, wf = trained_like_weights(rng), trained_like_weights(rng)
+    shape = dict(alpha_scale=300., sigma_bias=50., pe_decay=1.0) if field == 'sharp' else {}
+    wc, wf = trained_like_weights(rng, **shape), trained_like_weights(rng, **shape)
     models['model'].set_weights(wc)
     models['model_fine'].set_weights(wf)
     assert start == 0 and len(grad_vars) == 48
@@ -481,23 +521,37 @@ def test_render_rays_end_to_end(gpu, white_bkgd, lindisp):
     zc = ops.sample_z(rays11, 64, lindisp)
     raw_c = ops.mlp_forward_rays(models['model'].packed(), rays11, zc)
     _, _, _, w_c, _ = ops.composite_fwd(raw_c, zc, rays11[:, 3:6], 11, white_bkgd)
-    ok = ((raw_c[:, -1, 3].abs() > 5e-3) & (extras['raw'][:, -1, 3].abs() > 5e-3)).cpu().numpy()
+    edge = 5e-3 * max(1., float(raw_c[..., 3].abs().max()))   # the density's rounding is relative to its scale
+    ok = ((raw_c[:, -1, 3].abs() > edge) & (extras['raw'][:, -1, 3].abs() > edge)).cpu().numpy()
     assert ok.mean() > 0.9
     # coarse pass has no resampling in front of it: strict
-    np.testing.assert_allclose(extras['rgb0'].cpu().numpy()[ok], ref[3]['rgb0'][ok], atol=RGB_TOL)
-    np.testing.assert_allclose(extras['acc0'].cpu().numpy()[ok], ref[3]['acc0'][ok], atol=RGB_TOL)
+    e0 = np.abs(extras['rgb0'].cpu().numpy() - ref[3]['rgb0'])[ok]
+    a0 = np.abs(extras['acc0'].cpu().numpy() - ref[3]['acc0'])[ok]
+    print(f"{field}: coarse rgb0 error max {e0.max():.2e} q90 {np.quantile(e0.max(-1), 0.9):.2e}; acc0 max {a0.max():.2e}")
+    if field == 'sharp':
+        assert np.quantile(e0.max(-1), 0.9) < RGB_TOL and e0.max() < 2e-2 and a0.max() < 2e-2
+    else:
+        assert e0.max() < RGB_TOL and a0.max() < RGB_TOL
     zf, _, _ = ops.resample_merge(zc, w_c, 128, det=True)
     zf = zf.cpu().numpy().astype(np.float64)
     r11 = rays11.cpu().numpy().astype(np.float64)
     pts = r11[:, None, 0:3] + r11[:, None, 3:6] * zf[:, :, None]
     raw_f = orc.run_network(pts, r11[:, 8:11], wf, dtype=np.float64)
     rgb_stage = orc.raw2outputs(raw_f, zf, r11[:, 3:6], 0., white_bkgd, dtype=np.float64)[0]
-    np.testing.assert_allclose(rgb[ok], rgb_stage[ok], atol=RGB_TOL)
-    # (2) free-running
+    e_stage = np.abs(rgb - rgb_stage)[ok]
     err = np.abs(rgb - ref[0])[ok]
-    assert np.quantile(err, 0.99) < RGB_TOL and err.max() < 2e-2, (np.quantile(err, 0.99), err.max())
+    print(f"{field}: max|sigma| {np.abs(raw_f[..., 3]).max():.0f}; stage-wise rgb error max {e_stage.max():.2e} "
+          f"q90 {np.quantile(e_stage.max(-1), 0.9):.2e}; free-running max {err.max():.2e} q99 {np.quantile(err, 0.99):.2e}")
+    if field == 'sharp':
+        assert np.abs(raw_f[..., 3]).max() > 300.
+        assert np.quantile(e_stage.max(-1), 0.9) < RGB_TOL and e_stage.max() < 2e-2
+    else:
+        assert e_stage.max() < RGB_TOL
+        # (2) free-running
+        assert np.quantile(err, 0.99) < RGB_TOL and err.max() < 2e-2, (np.quantile(err, 0.99), err.max())
     target = np.clip(ref[0] + np.random.default_rng(0).normal(size=ref[0].shape) * 0.05, 0, 1)
     psnr = lambda x: -10. * np.log10(np.mean((x - target) ** 2))
+    print(f"{field}: PSNR delta {psnr(rgb) - psnr(ref[0]):+.4f} dB")
     assert abs(psnr(rgb) - psnr(ref[0])) <= 0.05  # every ray, knife edges included
 
 

@@ -152,12 +152,12 @@ def _mlp_grads_reference(ws, rb, z, d_raw, act):
     return [w.grad.numpy() for w in W], flips / (n_points * (8 * 256 + 128))
 
 
-@pytest.mark.parametrize("n,S", [(8, 64), (5, 192), (3, 37)])
-def test_mlp_backward(gpu, n, S):
+@pytest.mark.parametrize("n,S,scale_hidden", [(8, 64, 1.), (5, 192, 1.), (3, 37, 1.), (8, 64, 2.), (8, 64, 3.)])
+def test_mlp_backward(gpu, n, S, scale_hidden):
     from nerf_amd import ops
     from nerf_amd.run_nerf_helpers import init_nerf_model
     rng = np.random.default_rng(100 + n)
-    ws = trained_like_weights(rng)
+    ws = trained_like_weights(rng, scale_hidden=scale_hidden)
     m = init_nerf_model(8, 256, 63, 27, 4, [4], True, device=gpu)
     m.set_weights(ws)
     rb = synthetic_rays(n, seed=n)
@@ -182,11 +182,17 @@ def test_mlp_backward(gpu, n, S):
         rel = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
         assert rel < 5e-3, (name, rel)
         assert np.max(np.abs(g - r)) < 2e-2 * np.max(np.abs(r)) + 1e-12, name
-    # the automatic scale gives the same answer to rounding
+    # the automatic scale gives the same answer to rounding; kernels scaled 3x make the gradient
+    # grow by more than the 128x of headroom it leaves on the way down (x3 per layer), and that
+    # is reported, with NaN gradients, not returned as numbers
     auto = [torch.zeros_like(p) for p in m.params]
     ops.mlp_backward(pb, act, _t(d_raw, gpu), None, gbuf, part, auto)
-    assert ops.mlp_backward_status(part)[0] == 0
+    flags = ops.mlp_backward_status(part)[0]
+    assert flags == (ops.GRAD_SATURATED if scale_hidden >= 3. else 0)
     for name, g, r in zip(names, auto, ref):
+        if flags:
+            assert bool(torch.isnan(g).all()), name
+            continue
         rel = np.linalg.norm(g.cpu().numpy() - r) / max(np.linalg.norm(r), 1e-30)
         assert rel < 5e-3, (name, rel)
     # accumulate mode adds on top
@@ -294,7 +300,7 @@ def test_training_step_gradients_end_to_end(gpu, n):
     for m in models.values():
         flags, gs, mx = m.grad_status()
         assert flags == 0 and mx > 0
-        assert 1024. <= gs * mx < 2048. and np.log2(gs) == round(np.log2(gs))   # a power of two, on target
+        assert 256. <= gs * mx < 512. and np.log2(gs) == round(np.log2(gs))   # a power of two, on target
     # float64 autograd of the restatement, on the GPU, a slice of rays at a time
     t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=gpu)
     Wc = [t64(w).requires_grad_(True) for w in wc]
@@ -376,7 +382,7 @@ def test_gradient_scale_is_automatic_and_misuse_is_reported(gpu):
         return max(np.linalg.norm(g.cpu().numpy() - r) / max(np.linalg.norm(r), 1e-30) for g, r in zip(grads, ref))
 
     grads, (flags, gs, mx) = run(None)
-    assert flags == 0 and abs(mx - float(d_raw.abs().max())) < 1e-12 and 1024. <= gs * mx < 2048.
+    assert flags == 0 and abs(mx - float(d_raw.abs().max())) < 1e-12 and 256. <= gs * mx < 512.
     assert worst_rel(grads) < 5e-3
     # an explicit factor equal to the automatic one gives the same bits
     again, (flags2, gs2, _) = run(gs)

@@ -55,14 +55,27 @@ def synthetic_rays(n, seed=0, near=2., far=6.):
     return rb.astype(np.float32)
 
 
-def trained_like_weights(rng, scale_hidden=1.0, sigma_bias=0.5):
+def trained_like_weights(rng, scale_hidden=1.0, sigma_bias=0.5, alpha_scale=1.0, pe_decay=0.0):
     """Glorot-uniform weights (Keras default) with small non-zero biases so every bias path is
-    exercised; the alpha bias is raised a little so that rays are neither empty nor opaque."""
+    exercised; the alpha bias is raised a little so that rays are neither empty nor opaque.
+
+    Knobs that move the network away from its initialisation, towards what optimisation produces
+    (no trained weights exist offline): `scale_hidden` multiplies every kernel (activations grow
+    by that factor per layer); `alpha_scale` sharpens the density head (|sigma| in the hundreds,
+    as the histogram printed in the reference's extract_mesh.ipynb shows for a trained scene);
+    `pe_decay` > 0 damps the rows fed by octave k of the point encoding by 2^(-pe_decay k), the
+    spectral fall-off of a fitted field (with white-noise weights on sin(512 x) the field is a
+    different random number at every sample and any two arithmetics disagree after resampling)."""
     from oracle import nerf_oracle as orc
     ws = orc.init_nerf_weights(rng)
     for i in range(1, len(ws), 2):
         ws[i] = rng.uniform(-0.1, 0.1, size=ws[i].shape).astype(np.float32)
     for i in range(0, len(ws), 2):
         ws[i] = (ws[i] * scale_hidden).astype(np.float32)
+    if pe_decay > 0.:
+        for wi in (0, 10):           # layer 0 and the skip rows of layer 5: [x(3), (sin, cos)(6) per octave]
+            for k in range(10):
+                ws[wi][3 + 6 * k: 9 + 6 * k] *= np.float32(2.0 ** (-pe_decay * k))
+    ws[22] = (ws[22] * alpha_scale).astype(np.float32)
     ws[23] = ws[23] + np.float32(sigma_bias)
     return ws
