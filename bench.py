@@ -146,6 +146,55 @@ def train_leg(a, kw_train, models, dev, rank, world, fence):
             "final_loss": round(float(loss), 6)}
 
 
+def strong_leg(a, kw_test, dev, rank, world, fence):
+    """BASELINE config 4: ONE 800 x 800 novel view (640,000 rays, 64+128 samples, chunk 32768)
+    with the ray batch sharded over the ranks (contiguous slices, nerf_amd.parallel.render_sharded)
+    and one all-gather of the packed maps (rgb, disp, acc, depth: 24 B/ray) at the end.  Strong
+    scaling: the work is fixed, value = 640,000 x steps / time."""
+    from nerf_amd import ops, parallel
+    from nerf_amd.load_blender import pose_spherical
+    from nerf_amd.run_nerf import batchify_rays
+    H = W = 800
+    focal = .5 * W / np.tan(.5 * 0.6911112070083618)
+    c2w = torch.as_tensor(pose_spherical(-120., -30., 4.)[:3, :4])
+    o, d = ops.get_rays(H, W, focal, c2w)
+    rays_flat = ops.build_ray_batch(o, d, d, False, H, W, focal, 2., 6.)
+    kw = {k: v for k, v in kw_test.items() if k not in ('ndc', 'use_viewdirs')}
+    flat_fn = lambda r: batchify_rays(r, 1024 * 32, **kw)
+
+    def step():
+        return parallel.render_sharded(flat_fn, rays_flat)
+    out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    # the exchange alone: the same all-gather on already rendered maps
+    n = rays_flat.shape[0]
+    lo, hi = parallel.shard_bounds(n, rank, world)
+    packed = torch.cat([out['rgb_map'][lo:hi], out['disp_map'][lo:hi, None], out['acc_map'][lo:hi, None],
+                        out['depth_map'][lo:hi, None]], 1).contiguous()
+    parallel.gather_rows(packed, n)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        parallel.gather_rows(packed, n)
+    fence()
+    dg = time.perf_counter() - t1
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt, dg], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, dg = float(t[0].item()), float(t[1].item())
+    assert out['rgb_map'].shape == (n, 3) and bool(torch.isfinite(out['rgb_map']).all())
+    return {"workload": "one 800x800 view, 640000 rays, 64+128 samples, chunk 32768, ray batch sharded over the ranks",
+            "rays_per_s": round(n * a.steps / dt, 1), "ms_per_view": round(dt / a.steps * 1e3, 3),
+            "all_gather_ms": round(dg / a.steps * 1e3, 3), "gather_bytes_per_ray": 24, "scaling": "strong",
+            "rays_per_gpu": hi - lo, "steps": a.steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +205,8 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=16384, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=20, help="timed optimisation steps of the training leg (0 = skip)")
     ap.add_argument("--n-rand", type=int, default=4096, help="rays per GPU per optimisation step")
+    ap.add_argument("--mode", choices=("weak", "strong"), default="weak",
+                    help="headline: weak = every rank renders its own --rays batch; strong = one 800x800 view sharded over the ranks")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -213,6 +264,7 @@ def main():
     train = None
     if a.train_steps > 0:
         train = train_leg(a, kw_train, models, dev, rank, world, fence)
+    strong = strong_leg(a, kw_test, dev, rank, world, fence)
 
     mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
     mlp_points = sum(p for _, _, p in timing)
@@ -256,7 +308,13 @@ def main():
             "hbm_kernels": hbm_kernels,
             "cpu_baseline": cpu,
             "train": train,
+            "strong_800x800": strong,
         }
+        if a.mode == "strong":
+            out.update(value=strong["rays_per_s"], ms_per_step=strong["ms_per_view"], scaling="strong")
+            out["config"] = {"workload": strong["workload"], "rays_per_gpu": strong["rays_per_gpu"], "chunk": 32768,
+                             "networks": out["config"]["networks"], "parallelism": f"ray-sharded x{world}"}
+            out["weak_1M"] = {"rays_per_s": round(rays_per_s, 1), "ms_per_step": round(dt / a.steps * 1e3, 3)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -68,22 +68,36 @@ def render_sharded(render_flat_fn, rays_flat, keys=('rgb_map', 'disp_map', 'acc_
     return res
 
 
-class GradBucket:
-    """Flat fp32 view of a parameter list's gradients for a single all-reduce per step."""
+def global_count(n_local, device=None):
+    """Sum of `n_local` over the ranks (the global ray count of a sharded batch): one tiny
+    collective; 1-rank jobs return n_local without one."""
+    _, w = world()
+    if w == 1:
+        return int(n_local)
+    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
 
-    def __init__(self, params):
-        self.params = list(params)
-        self.sizes = [p.numel() for p in self.params]
-        self.flat = torch.zeros((sum(self.sizes),), dtype=torch.float32, device=self.params[0].device)
-        self.views, at = [], 0
-        for p, n in zip(self.params, self.sizes):
-            self.views.append(self.flat[at:at + n].view_as(p))
-            at += n
 
-    def allreduce_(self, group=None, async_op=False):
-        """SUM over ranks, in place.  Each rank's loss must already be divided by the GLOBAL ray
-        count so that the sum is the gradient of the global mean (run_nerf.py:781,:809-811)."""
-        _, w = world()
-        if w == 1:
-            return None
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+def allreduce_sum_(flat, async_op=False, group=None):
+    """SUM over the ranks, in place, of one flat fp32 buffer (a network's whole gradient: 2.38 MB,
+    one collective -- over xGMI the cost is latency, so never one call per tensor).  Each rank's
+    loss must already be divided by the GLOBAL ray count so that the sum is the gradient of the
+    global mean (run_nerf.py:781,:809-811).  Returns the work handle when async_op."""
+    _, w = world()
+    if w == 1:
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def broadcast_parameters(models, src=0):
+    """Makes every rank's networks bit-identical replicas of rank `src`'s (one broadcast of the
+    flat parameter buffer per network), e.g. after create_nerf drew the initial weights from each
+    rank's own generator or only one rank found a checkpoint."""
+    _, w = world()
+    if w == 1:
+        return
+    for m in models:
+        with torch.no_grad():
+            dist.broadcast(m.flat, src=src)
+        m.mark_dirty()

@@ -172,4 +172,7 @@ def create_nerf(args):
             ft_weights_fine = '{}_fine_{}'.format(ft_weights[:-11], ft_weights[-10:])
             print('Reloading fine from', ft_weights_fine)
             model_fine.set_weights(load_weights(ft_weights_fine))
+    # one process per GPU: every rank must hold the same replicas (each drew its own initial weights)
+    from . import parallel
+    parallel.broadcast_parameters(models.values())
     return render_kwargs_train, render_kwargs_test, start, grad_vars, models

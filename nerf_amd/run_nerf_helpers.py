@@ -132,7 +132,15 @@ class NerfModel:
         # max|d_raw| at every backward pass (what callers should leave it at)
         self.grad_scale = None
         self._grad_partial = None  # scratch of the last backward pass; its head is the status block
+        self._grad_flat = None     # flat gradient buffer of the last backward pass (24 views tile it)
+        self._grad_work = None     # pending all-reduce of that buffer under data parallelism
+        self._grad_epoch = -1
         _MODELS_BY_STORAGE[self.flat.data_ptr()] = self
+
+    @staticmethod
+    def live():
+        """The networks that currently exist in this process."""
+        return list(_MODELS_BY_STORAGE.values())
 
     # Keras-like surface
     @property

@@ -24,6 +24,7 @@ from . import ops
 from . import parallel
 
 _TAPE_DEPTH = 0
+_TAPE_EPOCH = 0   # bumped when a tape opens: a network's reusable gradient buffer is handed out once per tape
 
 
 def recording():
@@ -35,8 +36,9 @@ class GradientTape:
     """Context manager with tf.GradientTape's two-call surface (run_nerf.py:770, :825)."""
 
     def __enter__(self):
-        global _TAPE_DEPTH
+        global _TAPE_DEPTH, _TAPE_EPOCH
         _TAPE_DEPTH += 1
+        _TAPE_EPOCH += 1
         self._grad_mode = torch.enable_grad()
         self._grad_mode.__enter__()
         return self
@@ -80,13 +82,29 @@ class MLPQuery(torch.autograd.Function):
         partial = model._grad_partial
         if partial is None or partial.device != dev or partial.numel() < ops.partial_bytes():
             partial = model._grad_partial = torch.empty((ops.partial_bytes(),), dtype=torch.uint8, device=dev)
-        flat = torch.empty_like(model.flat)
+        # The network's whole gradient is ONE flat buffer (the 24 tensors are views): Adam reads it
+        # with one launch and data-parallel ranks exchange it with one collective.  The buffer is
+        # kept and reused from step to step; a network queried twice under one tape (coarse
+        # network doing the fine pass too) gets a fresh one the second time, autograd adds them.
+        first_use = getattr(model, '_grad_epoch', -1) != _TAPE_EPOCH
+        if first_use and getattr(model, '_grad_flat', None) is not None and model._grad_flat.device == dev:
+            flat = model._grad_flat
+        else:
+            flat = torch.empty_like(model.flat)
+            if first_use:
+                model._grad_flat = flat
         grads, at = [], 0
         for p in model.params:
             grads.append(flat[at:at + p.numel()].view(p.shape))
             at += p.numel()
         ops.mlp_backward(model.packed_bwd(), ctx.act, d_raw, model.grad_scale, gbuf, partial, grads)
         ctx.act = None
+        if first_use:
+            model._grad_epoch = _TAPE_EPOCH
+            # data parallel: start this network's all-reduce now, so that the fine network's
+            # exchange runs beside the coarse network's backward pass (autograd reaches the fine
+            # network first); train_step waits for the handles before the optimiser step
+            model._grad_work = parallel.allreduce_sum_(flat, async_op=True) if DP_OVERLAP else None
         return (None, None, None) + tuple(grads)
 
 
@@ -250,30 +268,74 @@ class Adam:
 
 
 # ---- data parallel ---------------------------------------------------------------------------
-def allreduce_gradients(grads, average=True):
-    """Ray-sharded data parallelism: SUM the gradients of every rank with ONE collective over a
-    flat 4.77 MB bucket (RCCL over xGMI: latency-bound, so never one call per tensor), then divide
-    by the world size so that equal shards reproduce the global-mean loss gradient."""
+# Ray-sharded data parallelism.  Every rank divides its loss by the GLOBAL ray count
+# (dp_loss_weight), so the SUM of the ranks' gradients is the gradient of the global mean loss
+# whatever the shard sizes; nothing is divided afterwards.
+DP_OVERLAP = True   # start a network's all-reduce inside its backward node (see MLPQuery.backward)
+
+
+def dp_loss_weight(n_local, device=None):
+    """n_local / n_global: what a rank multiplies its local MEAN loss by."""
+    _, world_size = parallel.world()
+    if world_size == 1:
+        return 1.0
+    n_global = parallel.global_count(n_local, device)
+    return float(n_local) / float(max(n_global, 1))
+
+
+def allreduce_gradients(grads):
+    """SUM over the ranks of a list of gradient tensors, with ONE collective per flat buffer they
+    tile (a network's 24 gradients are views of one 2.38 MB buffer: no copy, no per-tensor call);
+    tensors that are not views of a common buffer are packed into one bucket first.  Exchanges
+    already started by the backward nodes (DP_OVERLAP) are only waited for.  Returns the list."""
     rank, world_size = parallel.world()
     if world_size == 1:
         return grads
-    import torch.distributed as dist
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    if average:
-        flat /= world_size
-    out, at = [], 0
-    for g in grads:
-        out.append(flat[at:at + g.numel()].view(g.shape))
-        at += g.numel()
+    from .run_nerf_helpers import NerfModel
+    pending = [m for m in NerfModel.live() if getattr(m, '_grad_work', None) is not None]
+    done = set()
+    for m in pending:
+        m._grad_work.wait()
+        m._grad_work = None
+        done.add(m._grad_flat.data_ptr())
+    groups, loose = {}, []
+    for i, g in enumerate(grads):
+        base = g._base if g._base is not None else g
+        if base.dim() == 1 and base.is_contiguous() and base.dtype == torch.float32:
+            groups.setdefault(base.data_ptr(), [base, []])[1].append(i)
+        else:
+            loose.append(i)
+    out = list(grads)
+    for ptr, (base, idx) in groups.items():
+        covered = sum(grads[i].numel() for i in idx) == base.numel()
+        if not covered:
+            loose += idx
+        elif ptr not in done:
+            parallel.allreduce_sum_(base)
+    if loose:
+        flat = torch.cat([grads[i].reshape(-1) for i in loose])
+        parallel.allreduce_sum_(flat)
+        at = 0
+        for i in loose:
+            out[i] = flat[at:at + grads[i].numel()].view(grads[i].shape)
+            at += grads[i].numel()
     return out
 
 
 def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=()):
     """One optimisation step as the reference performs it (run_nerf.py:770-826, the plain
     photometric configuration): returns (loss, psnr, psnr0) as 0-d tensors.
-    render_fn(rays) must call render(..., rays=rays, **render_kwargs_train)."""
+    render_fn(rays) must call render(..., rays=rays, **render_kwargs_train).
+
+    Under torch.distributed every rank passes ITS shard of the batch; the losses are weighted by
+    n_local / n_global, the gradients summed over the ranks, and the returned loss is the global
+    mean (psnr / psnr0 are those of the local shard)."""
     from .run_nerf_helpers import img2mse, mse2psnr
+    _, world_size = parallel.world()
+    weight = 1.0
+    if world_size > 1:
+        n_local = int(target_s.shape[0]) if hasattr(target_s, 'shape') else len(target_s)
+        weight = dp_loss_weight(n_local, batch_rays[0].device if isinstance(batch_rays[0], torch.Tensor) else None)
     with GradientTape() as tape:
         rgb, disp, acc, extras = render_fn(batch_rays)
         img_loss = img2mse(rgb, target_s)
@@ -284,7 +346,14 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
             img_loss0 = img2mse(extras['rgb0'], target_s)
             loss = loss + img_loss0
             psnr0 = mse2psnr(img_loss0.detach())
+        if weight != 1.0:
+            loss = loss * weight
     gradients = tape.gradient(loss, grad_vars)
     gradients = allreduce_gradients(gradients)
     optimizer.apply_gradients(zip(gradients, grad_vars))
-    return loss.detach(), psnr, psnr0
+    loss = loss.detach()
+    if world_size > 1:
+        import torch.distributed as dist
+        loss = loss.clone()
+        dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+    return loss, psnr, psnr0

@@ -148,24 +148,46 @@ def _worker(rank, world_size, port, tmp):
         for k in full:
             assert out[k].shape == full[k].shape, k
             assert torch.equal(out[k], full[k]), k
-        # data-parallel gradient: each rank's loss is divided by the GLOBAL ray count, SUM all-reduce
+        # data-parallel gradient, the product's own functions on CPU tensors: unequal shards (501 /
+        # 500 rays), each rank's MEAN loss weighted by n_local / n_global, SUM all-reduce of the flat
+        # gradient buffer in place -> the gradient of the global mean
+        from nerf_amd import training
         w = torch.nn.Parameter(torch.ones(11, 3))
         b = torch.nn.Parameter(torch.zeros(3))
         target = torch.rand((n, 3), generator=g)
         mine = parallel.shard_rays(rays)
         lo, hi = parallel.shard_bounds(n, rank, world_size)
-        loss = ((mine @ w + b - target[lo:hi]) ** 2).sum() / (n * 3)
+        assert parallel.global_count(hi - lo) == n
+        weight = training.dp_loss_weight(hi - lo)
+        assert abs(weight - (hi - lo) / n) < 1e-12
+        loss = ((mine @ w + b - target[lo:hi]) ** 2).mean() * weight
         gw, gb = torch.autograd.grad(loss, [w, b])
-        bucket = parallel.GradBucket([w, b])
-        bucket.views[0].copy_(gw)
-        bucket.views[1].copy_(gb)
-        bucket.allreduce_()
+        flat = torch.zeros(36)
+        views = [flat[:33].view(11, 3), flat[33:]]
+        views[0].copy_(gw)
+        views[1].copy_(gb)
+        out = training.allreduce_gradients(views)
+        assert out[0].data_ptr() == flat.data_ptr() and out[1].data_ptr() == views[1].data_ptr()   # in place, one bucket
         w2 = torch.nn.Parameter(torch.ones(11, 3))
         b2 = torch.nn.Parameter(torch.zeros(3))
         loss_full = ((rays @ w2 + b2 - target) ** 2).mean()
         fw, fb = torch.autograd.grad(loss_full, [w2, b2])
-        assert torch.allclose(bucket.views[0], fw, atol=1e-6)
-        assert torch.allclose(bucket.views[1], fb, atol=1e-6)
+        assert torch.allclose(out[0], fw, atol=1e-6) and torch.allclose(out[1], fb, atol=1e-6)
+        # tensors that do not tile one buffer are packed into one bucket
+        out2 = training.allreduce_gradients([gw.clone(), gb.clone()])
+        assert torch.allclose(out2[0], fw, atol=1e-6) and torch.allclose(out2[1], fb, atol=1e-6)
+        # the averaged loss a step reports, and identical replicas after a broadcast
+
+        class Net:
+            def __init__(self, seed):
+                self.flat = torch.rand(7, generator=torch.Generator().manual_seed(seed))
+                self.dirty = 0
+
+            def mark_dirty(self):
+                self.dirty += 1
+        net = Net(100 + rank)
+        parallel.broadcast_parameters([net])
+        assert torch.equal(net.flat, Net(100).flat) and net.dirty == 1
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -437,3 +437,87 @@ def test_training_reduces_loss(gpu):
     with torch.no_grad():
         rgb, _, _, _ = render(1, 1, 1., chunk=1024 * 32, rays=rays, near=2., far=6., **kw_test)
     assert float(torch.mean((rgb - target) ** 2)) < losses[0]
+
+
+def _dp_worker(rank, world_size, port, tmp):
+    """One of two data-parallel ranks sharing the one GPU of the box (gloo moves the device
+    tensors; on a multi-GPU node the same code runs over RCCL)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from nerf_amd import parallel, training
+    from nerf_amd.run_nerf import create_nerf, render
+    from tests.util import default_args
+    torch.cuda.set_device(0)
+    gpu = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
+    try:
+        torch.manual_seed(1234 + rank)          # different initial weights per rank: create_nerf must broadcast
+        args = default_args(white_bkgd=True, perturb=1.)
+        kw_train, kw_test, _, grad_vars, models = create_nerf(args)
+        nets = [models['model'], models['model_fine']]
+        start = [m.flat.detach().clone() for m in nets]
+        both = [torch.empty_like(start[0]) for _ in range(world_size)]
+        dist.all_gather(both, start[0])
+        assert torch.equal(both[0], both[1]), "replicas differ after create_nerf"
+        n = 97                                  # shards of 49 and 48 rays
+        rb = synthetic_rays(n, seed=3)
+        rng = np.random.default_rng(5)
+        target = rng.uniform(size=(n, 3)).astype(np.float32)
+        pu = rng.uniform(size=(n, 64)).astype(np.float32)
+        uu = rng.uniform(size=(n, 128)).astype(np.float32)
+        lo, hi = parallel.shard_bounds(n, rank, world_size)
+
+        def fn_for(sl):
+            return lambda r: render(1, 1, 1., chunk=1024, rays=r, near=2., far=6., retraw=True,
+                                    perturb_u=_t(pu[sl], gpu), pdf_u=_t(uu[sl], gpu), **kw_train)
+        # reference: the whole batch on this rank alone, no exchange
+        from nerf_amd.run_nerf_helpers import img2mse
+        training.DP_OVERLAP = False
+        with training.GradientTape() as tape:
+            rgb, _, _, ex = fn_for(slice(0, n))((_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)))
+            full_loss = img2mse(rgb, _t(target, gpu)) + img2mse(ex['rgb0'], _t(target, gpu))
+        full = [g.clone() for g in tape.gradient(full_loss, grad_vars)]
+        training.DP_OVERLAP = True
+        # the data-parallel step on this rank's shard
+        seen = {}
+
+        class Probe(training.Adam):
+            def apply_gradients(self, gv):
+                gv = list(gv)
+                seen['grads'] = [g.clone() for g, _ in gv]
+                super().apply_gradients(gv)
+        opt = Probe(training.ExponentialDecay(5e-4, 250 * 1000, 0.1))
+        sl = slice(lo, hi)
+        loss, psnr, psnr0 = training.train_step(fn_for(sl), (_t(rb[sl, :3], gpu), _t(rb[sl, 3:6], gpu)),
+                                                _t(target[sl], gpu), grad_vars, opt)
+        np.testing.assert_allclose(float(loss), float(full_loss), rtol=1e-4)      # the global mean loss
+        for lo_i, hi_i, name in [(0, 24, 'coarse'), (24, 48, 'fine')]:
+            a = torch.cat([g.reshape(-1) for g in seen['grads'][lo_i:hi_i]]).double()
+            b = torch.cat([g.reshape(-1) for g in full[lo_i:hi_i]]).double()
+            rel = float((a - b).norm() / b.norm())
+            assert rel < 2e-3, (name, rel)      # same sum, split differently over fp16 chains
+        # both replicas took the same step
+        for m, s0 in zip(nets, start):
+            assert not torch.equal(m.flat, s0)
+            dist.all_gather(both, m.flat.detach())
+            assert torch.equal(both[0], both[1]), "replicas diverged"
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_train_step_two_ranks(gpu, tmp_path):
+    """training.train_step under torch.distributed with world_size 2 and unequal shards: the
+    summed gradient equals the single-rank gradient of the whole batch, the reported loss is the
+    global mean, and the replicas stay bit-identical."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
