@@ -147,6 +147,27 @@ int nerf_resample_merge(const float* z_vals, const float* weights, int64_t n, in
                         int det, const float* u, float* z_out, float* z_samples, float* z_std,
                         nerf_stream_t stream);
 
+/* ---- the whole per-ray core in one call ----------------------------------------------------- */
+
+/* Bytes of workspace nerf_render_rays needs (depths, network outputs and weights of both passes). */
+size_t nerf_render_rays_workspace_bytes(int64_t n_rays, int N_samples, int N_importance);
+
+/* render_rays (NERFCO.nerf_renderer.render_rays, source absent from the reference tree; call site
+ * run_nerf.py:20 inside batchify_rays, keyword arguments run_nerf.py:216-238) at
+ * raw_noise_std = 0: stratified depths (perturb_u [n,N_samples] uniforms or NULL = no jitter),
+ * coarse network, raw2outputs, sample_pdf on the inner weights + sorted merge (pdf_u
+ * [n,N_importance] uniforms or NULL = deterministic, i.e. perturb == 0), fine network
+ * (packed_fine, or packed_coarse when NULL), raw2outputs.  rays: [n,width>=11] ray batch as
+ * render() assembles it.  Outputs: rgb_map [n,3] (required), disp_map / acc_map / depth_map [n],
+ * and with N_importance > 0 the coarse pass's rgb0 [n,3], disp0, acc0 [n] and z_std [n]; any of
+ * them may be NULL.  With N_importance == 0 the maps are the coarse pass's and the last four are
+ * not written.  Six launches on `stream`, bit-identical to calling the stages one by one. */
+int nerf_render_rays(const void* packed_coarse, const void* packed_fine, const float* rays, int width,
+                     int64_t n_rays, int N_samples, int N_importance, int lindisp, int white_bkgd,
+                     const float* perturb_u, const float* pdf_u, float* rgb_map, float* disp_map,
+                     float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0, float* z_std,
+                     void* workspace, nerf_stream_t stream);
+
 /* ---- training: backward of the path (run_nerf.py:770-826, tf.GradientTape over render()) ---- */
 
 /* Gradient of raw2outputs: d_raw [n,S,4] from the gradients of rgb_map [n,3], acc_map [n] and

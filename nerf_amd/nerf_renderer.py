@@ -15,6 +15,9 @@ from . import training
 from .run_nerf_helpers import NerfModel
 
 
+SINGLE_CALL = True  # inference through nerf_render_rays (one C-ABI call per chunk) when nothing else is asked for
+
+
 def _check_embedders(embed_fn, embeddirs_fn):
     m = getattr(embed_fn, 'multires', None)
     mv = getattr(embeddirs_fn, 'multires', None)
@@ -74,6 +77,33 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     if rec and not fused:
         raise NotImplementedError("render_rays: gradients need the network_query_fn built by create_nerf")
 
+    if perturb > 0.:
+        if perturb_u is None:
+            perturb_u = torch.rand((n, N_samples), dtype=torch.float32, device=rays.device)
+        perturb_u = nv.f32(perturb_u, rays.device)
+        if tuple(perturb_u.shape) != (n, N_samples):
+            raise ValueError(f"render_rays: perturb_u must be [{n},{N_samples}]")
+    else:
+        perturb_u = None
+
+    # Inference with nothing to hand back but the maps: the whole core is one call of the C ABI
+    # (same six launches, intermediates in a workspace).  Per-stage calls remain for the tape, for
+    # `retraw`, for density noise, for foreign network_query_fn's and while bench.py's per-kernel
+    # timers are armed.
+    if (SINGLE_CALL and fused and not rec and not retraw and not raw_noise_std > 0. and n > 0
+            and ops.MLP_TIMING is None and ops.HBM_TIMING is None
+            and isinstance(network_fn, NerfModel) and (network_fine is None or isinstance(network_fine, NerfModel))):
+        if N_importance > 0 and perturb > 0.:
+            if pdf_u is None:
+                pdf_u = torch.rand((n, N_importance), dtype=torch.float32, device=rays.device)
+            pdf_u = nv.f32(pdf_u, rays.device)
+            if tuple(pdf_u.shape) != (n, N_importance):
+                raise ValueError(f"render_rays: pdf_u must be [{n},{N_importance}]")
+        else:
+            pdf_u = None
+        return ops.render_rays_single_call(network_fn.packed(), network_fine.packed() if network_fine is not None else None,
+                                           rays, N_samples, N_importance, lindisp, white_bkgd, perturb_u, pdf_u)
+
     def query(z, net):
         if rec:
             return training.MLPQuery.apply(rays, z, net, *net.params)
@@ -95,9 +125,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             return training.Composite.apply(raw, z, rays, bool(white_bkgd), noise, float(raw_noise_std))
         return ops.composite_fwd(raw, z, rays[:, 3:6], width, white_bkgd, noise, raw_noise_std)
 
-    if perturb > 0. and perturb_u is None:
-        perturb_u = torch.rand((n, N_samples), dtype=torch.float32, device=rays.device)
-    z_vals = ops.sample_z(rays, N_samples, lindisp, perturb_u if perturb > 0. else None)
+    z_vals = ops.sample_z(rays, N_samples, lindisp, perturb_u)
     raw = query(z_vals, network_fn)
     rgb_map, disp_map, acc_map, weights, depth_map = composite(raw, z_vals, noise0)
     ret = {}

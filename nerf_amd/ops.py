@@ -276,6 +276,33 @@ def resample_merge(z_vals, weights, N_importance, det=True, u=None, want_samples
     return z_out, z_samples, z_std
 
 
+_RENDER_WS = {}  # device -> grow-only workspace of render_rays_single_call
+
+
+def render_rays_single_call(packed_coarse, packed_fine, rays, N_samples, N_importance, lindisp=False,
+                            white_bkgd=False, perturb_u=None, pdf_u=None):
+    """The whole per-ray core through ONE call of the C ABI (nerf_render_rays).  Returns the dict
+    render_rays returns at raw_noise_std = 0 without `raw`."""
+    n, width = rays.shape
+    dev = rays.device
+    need = int(nv.lib().nerf_render_rays_workspace_bytes(n, int(N_samples), int(N_importance)))
+    ws = _RENDER_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _RENDER_WS[dev] = torch.empty((max(need, 1),), dtype=torch.uint8, device=dev)
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    ret = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n), depth_map=new(n))
+    if N_importance > 0:
+        ret.update(rgb0=new(n, 3), disp0=new(n), acc0=new(n), z_std=new(n))
+    g = lambda k: nv.ptr(ret.get(k))
+    with torch.cuda.device(dev):
+        nv.check(nv.lib().nerf_render_rays(nv.ptr(packed_coarse), nv.ptr(packed_fine), nv.ptr(rays), width, n,
+                                           int(N_samples), int(N_importance), int(bool(lindisp)), int(bool(white_bkgd)),
+                                           nv.ptr(perturb_u), nv.ptr(pdf_u), g('rgb_map'), g('disp_map'), g('acc_map'),
+                                           g('depth_map'), g('rgb0'), g('disp0'), g('acc0'), g('z_std'), nv.ptr(ws),
+                                           nv.stream()), "nerf_render_rays")
+    return ret
+
+
 def composite_bwd(raw, z, rays_d, d_stride, white_bkgd, noise, noise_std, g_rgb, g_acc=None, g_depth=None):
     """d_raw [N,S,4] from the gradients of rgb_map / acc_map / depth_map (None = zero)."""
     n, S = z.shape

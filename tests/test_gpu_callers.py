@@ -361,3 +361,37 @@ def test_render_rays_with_density_noise(gpu):
     # a wrong-shaped noise array is rejected
     with pytest.raises(ValueError):
         render(1, 1, 1., chunk=50, rays=rays, near=2., far=6., noise0=_t(n0[:, :5], gpu), **kw_train)
+
+
+# ---- the whole core in one C-ABI call ----------------------------------------------------------------
+@pytest.mark.parametrize("Sc,Si,lindisp,white,random", [(64, 128, False, True, False), (64, 128, False, False, True),
+                                                        (40, 0, True, True, False), (256, 128, True, False, True)])
+def test_render_rays_single_call_equals_stagewise(gpu, Sc, Si, lindisp, white, random):
+    """nerf_render_rays (what render_rays uses for plain inference) gives the bits of the six
+    per-stage calls, with and without supplied uniforms, with and without a fine pass."""
+    from nerf_amd import nerf_renderer
+    args = default_args(white_bkgd=white, lindisp=lindisp, N_samples=Sc, N_importance=Si, perturb=1. if random else 0.)
+    kw_train, kw_test, _, models, wc, wf = _nets(args, 12) if Si > 0 else (None,) * 6
+    if Si == 0:
+        from nerf_amd.run_nerf import create_nerf
+        kw_train, kw_test, _, _, models = create_nerf(args)
+        models['model'].set_weights(trained_like_weights(np.random.default_rng(12)))
+    kw = dict(kw_train if random else kw_test)
+    n = 777
+    rays = _t(synthetic_rays(n, seed=13), gpu)
+    rng = np.random.default_rng(3)
+    if random:
+        kw.update(perturb_u=_t(rng.uniform(size=(n, Sc)), gpu), pdf_u=_t(rng.uniform(size=(n, max(Si, 1))), gpu) if Si else None)
+    for k in ('ndc', 'use_viewdirs'):
+        kw.pop(k, None)
+    try:
+        nerf_renderer.SINGLE_CALL = True
+        one = nerf_renderer.render_rays(rays, **kw)
+        nerf_renderer.SINGLE_CALL = False
+        six = nerf_renderer.render_rays(rays, **kw)
+    finally:
+        nerf_renderer.SINGLE_CALL = True
+    assert set(one) == set(six) and ('rgb0' in one) == (Si > 0)
+    for k in six:
+        assert one[k].shape == six[k].shape, k
+        assert torch.equal(torch.nan_to_num(one[k], nan=-1.), torch.nan_to_num(six[k], nan=-1.)), k
