@@ -168,6 +168,22 @@ int nerf_render_rays(const void* packed_coarse, const void* packed_fine, const f
                      float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0, float* z_std,
                      void* workspace, nerf_stream_t stream);
 
+/* nerf_render_rays without the workspace argument, for callers that cannot allocate device memory
+ * and have none to pass: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  It has no counterpart in the reference.  The intermediates live in a fixed
+ * 64 MiB array of the library's code object (nerf_render_rays_static_bytes()), which every GPU the
+ * library runs on holds until the process ends; a call whose
+ * nerf_render_rays_workspace_bytes(n_rays, N_samples, N_importance) exceeds it is rejected with
+ * NERF_E_UNSUPPORTED before anything is launched (about 12,000 rays at 64 + 128 samples).  The call
+ * allocates and frees nothing.  All calls on one GPU share the array: calls that overlap in time on
+ * one GPU (different streams or threads) race; calls on one stream, or on different GPUs, do not. */
+size_t nerf_render_rays_static_bytes(void);
+int nerf_render_rays_static(const void* packed_coarse, const void* packed_fine, const float* rays, int width,
+                            int64_t n_rays, int N_samples, int N_importance, int lindisp, int white_bkgd,
+                            const float* perturb_u, const float* pdf_u, float* rgb_map, float* disp_map,
+                            float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0, float* z_std,
+                            nerf_stream_t stream);
+
 /* ---- training: backward of the path (run_nerf.py:770-826, tf.GradientTape over render()) ---- */
 
 /* Gradient of raw2outputs: d_raw [n,S,4] from the gradients of rgb_map [n,3], acc_map [n] and

@@ -35,6 +35,8 @@ SIGNATURES = {
     "nerf_resample_merge": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "nerf_render_rays_workspace_bytes": (_c.c_size_t, [_L, _I, _I]),
     "nerf_render_rays": (_I, [_P, _P, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_render_rays_static_bytes": (_c.c_size_t, []),
+    "nerf_render_rays_static": (_I, [_P, _P, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_composite_bwd": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "nerf_mlp_act_bytes": (_c.c_size_t, [_L]),
     "nerf_mlp_forward_train": (_I, [_P, _P, _I, _P, _L, _I, _P, _P, _P]),

@@ -4,6 +4,7 @@
 // [n,S] weights) in a workspace instead of in tensors the host language allocates per stage.
 // The stages are the library's own entry points, so the results are bit-identical to calling them
 // one by one.
+#include <mutex>
 #include "common.h"
 
 namespace nerf {
@@ -85,4 +86,64 @@ NERF_API int nerf_render_rays(const void* packed_coarse, const void* packed_fine
     return render_rays_impl(packed_coarse, packed_fine, rays, width, n_rays, N_samples, N_importance, lindisp, white_bkgd,
                             perturb_u, pdf_u, rgb_map, disp_map, acc_map, depth_map, rgb0, disp0, acc0, z_std,
                             (char*)workspace, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same call for callers that cannot allocate device memory and have no workspace to give
+// (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the
+// intermediates live in a fixed array of the code object.  Each GPU the library runs on holds its
+// own copy of the array at its own address until the process ends; the address is looked up once
+// per device and only that pointer is ever passed on (the array's name is a host-side stand-in,
+// not a device address).  Every stage overwrites what it uses, so nothing has to be cleared
+// between calls; calls that overlap in time on one GPU would share the array and race.
+// ---------------------------------------------------------------------------------------------
+namespace nerf {
+
+constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+static std::mutex g_scratch_lock;
+static void* g_scratch_ptr[64] = {};  // per device
+
+// The current device's copy of `scratch` (looked up on first use, with that device current).
+static int static_scratch(char** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) return NERF_FAIL(NERF_E_UNSUPPORTED, "nerf_render_rays_static: no current device");
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return NERF_FAIL(e != hipSuccess ? (int)e : NERF_E_UNSUPPORTED, "nerf_render_rays_static: hipGetSymbolAddress: %s",
+                             hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = (char*)g_scratch_ptr[dev];
+    return 0;
+}
+
+}  // namespace nerf
+
+NERF_API size_t nerf_render_rays_static_bytes(void) { return kStaticScratchBytes; }
+
+NERF_API int nerf_render_rays_static(const void* packed_coarse, const void* packed_fine, const float* rays, int width,
+                                     int64_t n_rays, int N_samples, int N_importance, int lindisp, int white_bkgd,
+                                     const float* perturb_u, const float* pdf_u, float* rgb_map, float* disp_map,
+                                     float* acc_map, float* depth_map, float* rgb0, float* disp0, float* acc0,
+                                     float* z_std, nerf_stream_t stream) {
+    int rc = check_render_args("nerf_render_rays_static", packed_coarse, rays, width, n_rays, N_samples, N_importance, rgb_map);
+    if (rc) return rc;
+    if (n_rays == 0) return 0;
+    const size_t need = nerf_render_rays_workspace_bytes(n_rays, N_samples, N_importance);
+    if (need > kStaticScratchBytes)
+        return NERF_FAIL(NERF_E_UNSUPPORTED,
+                         "nerf_render_rays_static: %lld rays at %d + %d samples need %zu bytes of scratch, the built-in array "
+                         "holds %zu (use fewer rays per call, or nerf_render_rays with a workspace)",
+                         (long long)n_rays, N_samples, N_importance, need, kStaticScratchBytes);
+    char* ws = nullptr;
+    rc = static_scratch(&ws);
+    if (rc) return rc;
+    return render_rays_impl(packed_coarse, packed_fine, rays, width, n_rays, N_samples, N_importance, lindisp, white_bkgd,
+                            perturb_u, pdf_u, rgb_map, disp_map, acc_map, depth_map, rgb0, disp0, acc0, z_std, ws, stream);
 }

@@ -1,0 +1,75 @@
+"""nerf_render_rays_static: nerf_render_rays with its intermediates in a fixed array of the code
+object instead of a caller workspace, for callers that cannot allocate device memory."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import default_args, synthetic_rays, trained_like_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(x, gpu):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=gpu)
+
+
+def _same(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=-1.), torch.nan_to_num(b, nan=-1.))   # disp is NaN where acc == 0
+
+
+def test_render_rays_static_matches_workspace_form(gpu):
+    from nerf_amd import _native as nv
+    from nerf_amd.run_nerf import create_nerf
+    lib = nv.lib()
+    kw_train, kw_test, _, _, models = create_nerf(default_args(white_bkgd=True))
+    rng = np.random.default_rng(4)
+    models['model'].set_weights(trained_like_weights(rng))
+    models['model_fine'].set_weights(trained_like_weights(rng))
+    pc, pf = models['model'].packed(), models['model_fine'].packed()
+    Sc, Si = 64, 128
+    cap = int(lib.nerf_render_rays_static_bytes())
+    assert cap == 64 << 20
+
+    def outputs(n):
+        new = lambda *s: torch.full(s, float('inf'), dtype=torch.float32, device=gpu)
+        return [new(n, 3), new(n), new(n), new(n), new(n, 3), new(n), new(n), new(n)]
+
+    def run(n, seed, static, with_u):
+        rays = _t(synthetic_rays(n, seed=seed), gpu)
+        r = np.random.default_rng(seed)
+        pu = _t(r.uniform(size=(n, Sc)), gpu) if with_u else None
+        uu = _t(r.uniform(size=(n, Si)), gpu) if with_u else None
+        out = outputs(n)
+        args = [nv.ptr(pc), nv.ptr(pf), nv.ptr(rays), 11, n, Sc, Si, 0, 1, nv.ptr(pu), nv.ptr(uu)] + [nv.ptr(o) for o in out]
+        if static:
+            nv.check(lib.nerf_render_rays_static(*args, nv.stream()), "nerf_render_rays_static")
+        else:
+            need = int(lib.nerf_render_rays_workspace_bytes(n, Sc, Si))
+            ws = torch.empty((need,), dtype=torch.uint8, device=gpu)
+            nv.check(lib.nerf_render_rays(*args, nv.ptr(ws), nv.stream()), "nerf_render_rays")
+        torch.cuda.synchronize()
+        return out
+
+    # two calls in a row through the built-in array, the second on a smaller batch (the array
+    # still holds the first call's intermediates), each against the workspace form
+    n_big = 9000
+    assert int(lib.nerf_render_rays_workspace_bytes(n_big, Sc, Si)) <= cap
+    first = run(n_big, 1, True, False)
+    free_before = torch.cuda.mem_get_info()[0]
+    second = run(2500, 2, True, True)
+    assert torch.cuda.mem_get_info()[0] == free_before          # nothing was allocated on the device
+    for got, want in ((first, run(n_big, 1, False, False)), (second, run(2500, 2, False, True))):
+        for g, w in zip(got, want):
+            assert bool(torch.isfinite(torch.nan_to_num(g, nan=0.)).all())   # every output was written
+            assert _same(g, w)
+    # beyond the array: a clear error, nothing launched
+    n_over = cap // 5000 + 1000
+    assert int(lib.nerf_render_rays_workspace_bytes(n_over, Sc, Si)) > cap
+    rays = _t(synthetic_rays(16, seed=0), gpu)       # never read: the size check comes first
+    out = outputs(16)
+    rc = lib.nerf_render_rays_static(nv.ptr(pc), nv.ptr(pf), nv.ptr(rays), 11, n_over, Sc, Si, 0, 1, None, None,
+                                     *[nv.ptr(o) for o in out], nv.stream())
+    assert rc == -2 and b"built-in array" in lib.nerf_last_error()
+    assert bool(torch.isinf(out[0]).all())
