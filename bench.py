@@ -39,16 +39,43 @@ N_RAYS = 1024 * 1024
 N_SAMPLES, N_IMPORTANCE = 64, 128
 
 
-def pmc_traffic_per_launch(kernel="mlp_fwd_wide_kernel<0, false>"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes
-    (profiles/r01_pmc_summary.txt: FETCH_SIZE and WRITE_SIZE in KiB summed over n dispatches of the
-    same launch shapes as the default bench: 131072-ray chunks, coarse and fine launches in equal
-    number).  FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes).  None when
-    the summary is absent or unreadable: bench.py itself cannot collect counters."""
+KERNEL_SOURCES = ("mlp_forward_wide.hip", "mlp_common.h", "mlp_layout_wide.h", "mlp_layout.h", "common.h")
+
+
+def kernel_source_hash():
+    """sha256 over the sources the dominant kernel (mlp_fwd_wide_kernel) is built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "nerf_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_traffic_per_launch(kernel="mlp_fwd_wide_kernel<0, false>", summary=None):
+    """(HBM bytes per launch of the dominant kernel, note) from the newest committed rocprofv3
+    counter summary (profiles/rNN_pmc_summary.txt, written by tools/profile_round.sh: FETCH_SIZE and
+    WRITE_SIZE in KiB summed over n dispatches of the same launch shapes as the default bench --
+    131072-ray chunks, coarse and fine launches in equal number).  FETCH_SIZE is doubled (gfx950
+    tallies 128-byte read requests at 64 bytes).  bench.py cannot collect counters itself, so the
+    figure is only quoted when the summary was taken on the kernel sources of this tree (its first
+    line holds their hash); otherwise (None, reason)."""
+    import glob
+    if summary is None:
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+        if not found:
+            return None, "no counter summary under profiles/"
+        summary = found[-1]
     try:
-        text = open(os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")).read()
-    except OSError:
-        return None
+        text = open(summary).read()
+    except OSError as e:
+        return None, f"unreadable counter summary: {e}"
+    name = os.path.basename(summary)
+    first = text.splitlines()[0] if text else ""
+    if not first.startswith("# source_hash"):
+        return None, f"{name} does not record the kernel sources it was taken on"
+    if first.split()[-1] != kernel_source_hash():
+        return None, f"{name} was taken on other kernel sources than this tree's (re-run tools/profile_round.sh)"
     got = {}
     for section in text.split("== pass")[1:]:
         lines = section.splitlines()
@@ -63,8 +90,8 @@ def pmc_traffic_per_launch(kernel="mlp_fwd_wide_kernel<0, false>"):
                         got[parts[0]] = float(parts[1]) * 1024.0 / n
                 break
     if "FETCH_SIZE" not in got or "WRITE_SIZE" not in got:
-        return None
-    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]
+        return None, f"{name} holds no FETCH_SIZE / WRITE_SIZE for {kernel}"
+    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], f"{name}, same kernel sources"
 
 
 def synthetic_batch(n, seed, device):
@@ -280,6 +307,9 @@ def main():
                             "avg_launch_ms": round(ms / len(ev), 4), "share_of_step": round(ms * 1e-3 / dt, 5)})
 
     if rank == 0:
+        traffic, traffic_note = pmc_traffic_per_launch()
+        if not (a.chunk == 131072 and a.rays % a.chunk == 0):
+            traffic, traffic_note = None, "counter summary is for 131072-ray chunks"
         cpu = None
         if a.cpu_rays > 0:
             v, secs = cpu_baseline(a.cpu_rays)
@@ -298,8 +328,9 @@ def main():
                        "parallelism": f"ray-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         # bytes per launch from the committed counter passes (same launch shapes), not live
-                         "traffic": pmc_traffic_per_launch() if a.chunk == 131072 and a.rays % a.chunk == 0 else None,
+                         # bytes per launch from the committed counter passes (same launch shapes and
+                         # kernel sources), not live; null with the reason when they do not match
+                         "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": (mlp_points // max(1, len(timing))) * 20,
                          "kernel": "mlp_fwd_wide_kernel", "launches": len(timing),
                          "avg_launch_ms": round(mlp_ms / max(1, len(timing)), 4),

@@ -162,15 +162,17 @@ DEV void glds16_untracked_sbase(const void* base, unsigned lane_off, unsigned ld
 // kernel drains the queue before it ends).  Ring slots are compile-time (chunk % RING), so
 // NCHUNKS must be a multiple of RING; chunks NLOAD .. NCHUNKS-1 exist only as slot numbers
 // (nothing is loaded for them, nothing reads them).
-template <int NCHUNKS, int RING, int DEPTH, int NLOAD = NCHUNKS, bool WRAP = false>
+template <int NCHUNKS, int RING, int DEPTH, int NLOAD = NCHUNKS, bool WRAP = false, int WAVES = kWavesPerBlock>
 struct Stream {
+    static_assert(WAVES == 8 || WAVES == 16, "a chunk is 16 KiB: 2 or 1 KiB per wave");
+    static constexpr int kLoadsPerWave = kFragsPerChunk / WAVES;  // 1 KiB loads of one wave per chunk
     static_assert(DEPTH <= RING - 2 && kPrefetch <= 8, "ring slack");
     static_assert(!WRAP || NCHUNKS % RING == 0, "a wrapping stream keeps its slot phase");
     static_assert(NLOAD <= NCHUNKS && NCHUNKS - NLOAD <= 1, "at most one slot-only chunk");
     static constexpr int kRingBytes = RING * kChunkBytes;
     VmQueue& vm;
-    const char* gsrc;   // this wave's 2 KiB share of chunk 0 (wave-uniform: loads take it as a scalar base)
-    unsigned wr;        // LDS address of this wave's 2 KiB share of ring slot 0 (wave-uniform)
+    const char* gsrc;   // this wave's share of chunk 0 (wave-uniform: loads take it as a scalar base)
+    unsigned wr;        // LDS address of this wave's share of ring slot 0 (wave-uniform)
     int lane_off;       // lane * 16
     // This lane's read addresses of ring bytes 0 and 65536, kept as two opaque registers so that
     // every fragment read is base + 16-bit immediate (a ds_read offset ends at 65535; left to
@@ -181,9 +183,9 @@ struct Stream {
     half8 a[kPrefetch];
 
     DEV Stream(VmQueue& q, const char* packed, char* lds_base, int wave, int lane)
-        : vm(q), gsrc(packed + wave * (2 * kFragBytes)),
+        : vm(q), gsrc(packed + wave * (kLoadsPerWave * kFragBytes)),
           wr(__builtin_amdgcn_readfirstlane(
-              (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds_base + wave * (2 * kFragBytes)))),
+              (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds_base + wave * (kLoadsPerWave * kFragBytes)))),
           lane_off(lane * 16) {
         unsigned lo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds_base + lane * 16);
         unsigned hi = lo + 65536u;
@@ -199,8 +201,8 @@ struct Stream {
             const char* g = gsrc + (size_t)C * kChunkBytes;
             const unsigned l = wr + (C % RING) * kChunkBytes;
             glds16_untracked_sbase(g, (unsigned)lane_off, l);
-            glds16_untracked_sbase(g + kFragBytes, (unsigned)lane_off, l + kFragBytes);
-            vm.issued += 2;
+            if constexpr (kLoadsPerWave == 2) glds16_untracked_sbase(g + kFragBytes, (unsigned)lane_off, l + kFragBytes);
+            vm.issued += kLoadsPerWave;
         }
         mark[C % RING] = vm.issued;
     }
@@ -230,11 +232,11 @@ struct Stream {
     // WRAP, at the top of every pass (the first one included, after prologue()): restarts the
     // queue bookkeeping from constants, so that every wait of a pass is an immediate.  Chunks
     // 0 .. DEPTH-1 are in flight, issued in that order; whatever else was issued between them
-    // only makes the true distance of a chunk from the queue's tail larger than the 2 loads per
+    // only makes the true distance of a chunk from the queue's tail larger than the loads per
     // younger chunk assumed here, so the waits are at worst stricter than needed.
     DEV void rebase() {
         constexpr int kBase = 1 << 20;
-        static_for<0, DEPTH>([&](auto c) { mark[decltype(c)::value % RING] = kBase - 2 * (DEPTH - 1 - decltype(c)::value); });
+        static_for<0, DEPTH>([&](auto c) { mark[decltype(c)::value % RING] = kBase - kLoadsPerWave * (DEPTH - 1 - decltype(c)::value); });
         vm.issued = kBase;
         // a new value per pass as far as the compiler can tell: otherwise it computes the 64-bit
         // source address of every chunk once, outside the loop, and keeps them all in registers

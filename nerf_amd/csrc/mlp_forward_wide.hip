@@ -47,15 +47,24 @@ struct FwdWideArgs {
 constexpr int kWRing = 5;
 constexpr int kWDepth = 3;
 constexpr int kWRingChunks = lw::kChunks + 1;
-using WideStream = Stream<kWRingChunks, kWRing, kWDepth, lw::kChunks, true>;
-constexpr int kWRingBytes = WideStream::kRingBytes;
+template <int WAVES>
+using WideStreamT = Stream<kWRingChunks, kWRing, kWDepth, lw::kChunks, true, WAVES>;
+constexpr int kWRingBytes = WideStreamT<8>::kRingBytes;
+// Waves per workgroup of the inference kernel.  8 (two per SIMD): a wave's live state is 244
+// registers (two fragment sets of 2 x 8 x 4, encodings, accumulators, the A-fragment pipeline), so
+// 16 waves (four per SIMD, 128 registers each) spill 700 bytes per lane.  The training forward is
+// always 8 (its saved-activation buffer is sized in 256-point tiles).
+#ifndef NERF_FWD_WAVES
+#define NERF_FWD_WAVES 8
+#endif
 
 DEV f32x4 mfma_wide(half8 a, half8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+template <class STREAM>
 struct WidePipe {
-    WideStream& st;
+    STREAM& st;
     const char* bias;   // bias table in LDS, already offset by this lane group's 16 bytes
     f32x4 acc[2][2];    // [tile parity][point tile]
 };
@@ -173,8 +182,8 @@ static_assert(w_last_slice_step(2) < 2 && w_last_slice_step(4) < 4 && w_last_sli
 // point tile pt.  Every k-step is one scheduling region: two MFMAs, the LDS read of the A
 // fragment kPrefetch steps ahead, a slice of the previous tile and, late in the tile, the bias
 // seed of the next one.
-template <int F0, int NK, int T, class GetB, class Prev>
-DEV void wide_tile(WidePipe& p, GetB&& getB, const Prev& prev) {
+template <int F0, int NK, int T, class PIPE, class GetB, class Prev>
+DEV void wide_tile(PIPE& p, GetB&& getB, const Prev& prev) {
     static_for<0, NK>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const half8 a = p.st.template take<F0 + k>();
@@ -197,8 +206,8 @@ DEV void wide_tile(WidePipe& p, GetB&& getB, const Prev& prev) {
 // One layer of NT output tiles of NK k-steps; its output becomes fragments 0..NT/2-1 of `out`
 // (both point tiles).  `before` finishes the tile that preceded the layer; the returned object
 // finishes the layer's last tile.
-template <int F0, int NT, int NK, int T0, bool RELU, bool STORE, int ABLK, int MBLK, class GetB, class Prev>
-DEV auto wide_layer(WidePipe& p, const WSink& sink, unsigned* mk, half8* out, GetB&& getB, const Prev& before) {
+template <int F0, int NT, int NK, int T0, bool RELU, bool STORE, int ABLK, int MBLK, class PIPE, class GetB, class Prev>
+DEV auto wide_layer(PIPE& p, const WSink& sink, unsigned* mk, half8* out, GetB&& getB, const Prev& before) {
     wide_tile<F0, NK, T0>(p, getB, before);
     static_for<1, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
@@ -269,10 +278,10 @@ struct PointWords {
 struct RayCursor {
     int64_t base, q, dq, step;
     int r, dr, S;
-    DEV RayCursor(int64_t tile, int wave, int S_) : S(S_) {
-        base = tile * kPointsPerBlock + wave * kPointsPerWave;
+    DEV RayCursor(int64_t tile, int wave, int S_, int points_per_block) : S(S_) {
+        base = tile * points_per_block + wave * kPointsPerWave;
         q = base / S, r = (int)(base - q * S);
-        step = (int64_t)gridDim.x * kPointsPerBlock;
+        step = (int64_t)gridDim.x * points_per_block;
         dq = step / S, dr = (int)(step - dq * S);
     }
     DEV void advance() {
@@ -356,19 +365,21 @@ DEV void point_xyz(const PointWords& w, float (&x)[3], float (&vd)[3]) {
     }
 }
 
-template <int MODE, bool STORE>
-__global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
+template <int MODE, bool STORE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[kWRingBytes + lw::kBiasBytes];
+    constexpr int kPB = WAVES * kPointsPerWave;  // points per workgroup tile
+    using WideStream = WideStreamT<WAVES>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
-    const int64_t ntiles = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
+    const int64_t ntiles = (a.M + kPB - 1) / kPB;
     saturate_fp16_conversions();
 
     VmQueue vm;
     WideStream st(vm, a.packed, lds, wave, lane);
     // biases first (oldest in the queue), 1 KiB per wave-load, then the first chunks
-    for (int blk = wave; blk < lw::kBiasBytes / kFragBytes; blk += kWavesPerBlock)
+    for (int blk = wave; blk < lw::kBiasBytes / kFragBytes; blk += WAVES)
         glds16_untracked(a.packed + lw::kBiasOffset + blk * kFragBytes + lane * 16,
                          lds + kWRingBytes + blk * kFragBytes);
     st.prologue();
@@ -384,10 +395,10 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     // read is this register + an immediate (the table lies beyond a ds_read's 16-bit offset)
     unsigned bias_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + kWRingBytes + g * 16);
     asm volatile("" : "+v"(bias_addr));
-    WidePipe pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}};
+    WidePipe<WideStream> pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}};
 
     // ---- this lane's two query points (one per point tile) of the workgroup's first tile ----
-    RayCursor where(blockIdx.x, wave, a.S);
+    RayCursor where(blockIdx.x, wave, a.S, kPB);
     PointWords cur[2] = {load_point<MODE>(a, where, lane, 0), load_point<MODE>(a, where, lane, 1)};
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
         WSink sink{nullptr, &vm};
         const char* act_tile = nullptr;  // this wave's tile of saved activations (wave-uniform)
         if constexpr (STORE) {
-            const int64_t wave_tile = tile * kWavesPerBlock + wave;
+            const int64_t wave_tile = tile * WAVES + wave;
             act_tile = a.act + (size_t)wave_tile * kActBlocks * kFragBytes;
             sink.base = a.act + (size_t)wave_tile * kActBlocks * kFragBytes + lane * 16;
             static_for<0, 2>([&](auto sc) {
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
             const f32x4& c = pp.acc[lw::T_RGB & 1][pt];
             // the lane id is read afresh: neither it nor the point index is worth registers through the network
             const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            const int64_t p = tile * kPointsPerBlock + wave * kPointsPerWave + 16 * pt + (ln & 15);
+            const int64_t p = tile * kPB + wave * kPointsPerWave + 16 * pt + (ln & 15);
             if (p < a.M && (ln >> 4) == 0) a.raw[p] = make_float4(c[0], c[1], c[2], sigma[pt]);
         }
         st.finish_pass();
@@ -480,18 +491,20 @@ __global__ __launch_bounds__(512) void mlp_fwd_wide_kernel(FwdWideArgs a) {
 }
 
 static int launch_fwd_wide(const FwdWideArgs& a, int mode, hipStream_t st, const char* what) {
-    const int64_t tiles = (a.M + kPointsPerBlock - 1) / kPointsPerBlock;
+    constexpr int kInferWaves = NERF_FWD_WAVES;
+    const int64_t tiles = a.act ? (a.M + kPointsPerBlock - 1) / kPointsPerBlock
+                                : (a.M + kInferWaves * kPointsPerWave - 1) / (kInferWaves * kPointsPerWave);
     if (a.S > (1 << 24)) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: more than 2^24 points per ray (%d)", what, a.S);
     // persistent workgroups: one per CU (the ring and two waves per SIMD fill a CU), fewer for small calls
     const int cus = device_cu_count();
     if (cus <= 0) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: no current device", what);
     const int64_t blocks = tiles < cus ? tiles : cus;
     if (a.act)
-        mlp_fwd_wide_kernel<0, true><<<(unsigned)blocks, 512, 0, st>>>(a);
+        mlp_fwd_wide_kernel<0, true, kWavesPerBlock><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(a);
     else if (mode == 0)
-        mlp_fwd_wide_kernel<0, false><<<(unsigned)blocks, 512, 0, st>>>(a);
+        mlp_fwd_wide_kernel<0, false, kInferWaves><<<(unsigned)blocks, kInferWaves * 64, 0, st>>>(a);
     else
-        mlp_fwd_wide_kernel<1, false><<<(unsigned)blocks, 512, 0, st>>>(a);
+        mlp_fwd_wide_kernel<1, false, kInferWaves><<<(unsigned)blocks, kInferWaves * 64, 0, st>>>(a);
     return check_launch(what);
 }
 

@@ -66,6 +66,7 @@ __host__ __device__ inline float auto_gscale(unsigned absmax_bits) {
 
 __global__ __launch_bounds__(256) void draw_absmax_kernel(const float4* __restrict__ d_raw, int64_t n,
                                                           unsigned* __restrict__ status) {
+    __shared__ unsigned part[4];
     unsigned m = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = d_raw[i];
@@ -80,7 +81,15 @@ __global__ __launch_bounds__(256) void draw_absmax_kernel(const float4* __restri
         const unsigned o = (unsigned)__shfl_xor((int)m, off);
         m = m > o ? m : o;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(status + ST_ABSMAX, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup (a few hundred on one word; one per wave of a large batch would
+    // queue thousands behind each other)
+    if (threadIdx.x == 0) {
+        const unsigned a = part[0] > part[1] ? part[0] : part[1], b = part[2] > part[3] ? part[2] : part[3];
+        const unsigned all = a > b ? a : b;
+        if (all) atomicMax(status + ST_ABSMAX, all);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -975,7 +984,7 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     if (e != hipSuccess) return NERF_FAIL((int)e, "nerf_mlp_backward(memset): %s", hipGetErrorString(e));
     {
         const int64_t want = (n_points + 255) / 256;
-        draw_absmax_kernel<<<(unsigned)(want < 2048 ? want : 2048), 256, 0, st>>>((const float4*)d_raw, n_points, status);
+        draw_absmax_kernel<<<(unsigned)(want < 512 ? want : 512), 256, 0, st>>>((const float4*)d_raw, n_points, status);
         int rc = check_launch("nerf_mlp_backward(absmax)");
         if (rc) return rc;
     }

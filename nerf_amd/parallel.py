@@ -69,14 +69,14 @@ def render_sharded(render_flat_fn, rays_flat, keys=('rgb_map', 'disp_map', 'acc_
 
 
 def global_count(n_local, device=None):
-    """Sum of `n_local` over the ranks (the global ray count of a sharded batch): one tiny
-    collective; 1-rank jobs return n_local without one."""
+    """Sum of `n_local` over the ranks (the global ray count of a sharded batch) as a 0-d float64
+    tensor on `device`: one tiny collective and no host synchronisation (the optimisation loop must
+    not wait for the GPU every step); 1-rank jobs need no collective."""
+    t = torch.tensor(float(n_local), dtype=torch.float64, device=device)
     _, w = world()
-    if w == 1:
-        return int(n_local)
-    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return int(round(float(t.item())))
+    if w > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
 
 
 def allreduce_sum_(flat, async_op=False, group=None):

@@ -275,12 +275,14 @@ DP_OVERLAP = True   # start a network's all-reduce inside its backward node (see
 
 
 def dp_loss_weight(n_local, device=None):
-    """n_local / n_global: what a rank multiplies its local MEAN loss by."""
+    """n_local / n_global: what a rank multiplies its local MEAN loss by.  A python float on one
+    rank; a 0-d fp32 tensor on `device` otherwise (formed from an all-reduced count, never read
+    back to the host)."""
     _, world_size = parallel.world()
     if world_size == 1:
         return 1.0
     n_global = parallel.global_count(n_local, device)
-    return float(n_local) / float(max(n_global, 1))
+    return (float(n_local) / n_global.clamp_min(1.)).to(torch.float32)
 
 
 def allreduce_gradients(grads):
@@ -346,7 +348,7 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
             img_loss0 = img2mse(extras['rgb0'], target_s)
             loss = loss + img_loss0
             psnr0 = mse2psnr(img_loss0.detach())
-        if weight != 1.0:
+        if world_size > 1:
             loss = loss * weight
     gradients = tape.gradient(loss, grad_vars)
     gradients = allreduce_gradients(gradients)

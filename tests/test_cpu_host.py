@@ -157,9 +157,9 @@ def _worker(rank, world_size, port, tmp):
         target = torch.rand((n, 3), generator=g)
         mine = parallel.shard_rays(rays)
         lo, hi = parallel.shard_bounds(n, rank, world_size)
-        assert parallel.global_count(hi - lo) == n
+        assert float(parallel.global_count(hi - lo)) == n
         weight = training.dp_loss_weight(hi - lo)
-        assert abs(weight - (hi - lo) / n) < 1e-12
+        assert weight.dtype == torch.float32 and abs(float(weight) - (hi - lo) / n) < 1e-7
         loss = ((mine @ w + b - target[lo:hi]) ** 2).mean() * weight
         gw, gb = torch.autograd.grad(loss, [w, b])
         flat = torch.zeros(36)
@@ -204,15 +204,32 @@ def test_ray_sharding_two_ranks_gloo(tmp_path):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
-def test_bench_reads_traffic_from_committed_counter_summary():
-    """bench.py's roofline.traffic comes from profiles/r01_pmc_summary.txt: it parses, and lies
-    within 25 % of the kernel's algorithmic bytes per launch (20 B/point, 16,777,216 points)."""
+def test_bench_quotes_counter_traffic_only_for_matching_kernel_sources(tmp_path):
+    """bench.py's roofline.traffic comes from a committed rocprofv3 counter summary and is quoted
+    only when that summary was taken on this tree's kernel sources (hash in its first line)."""
     import importlib.util
-    import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    t = bench.pmc_traffic_per_launch()
-    assert t is not None and 0.75 < t / (16777216 * 20) < 1.25
-    assert bench.pmc_traffic_per_launch("no_such_kernel") is None
+    body = ("== pass sq: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false>: n=8 total_ms=109.0 vgpr=124/0\n"
+            "    SQ_WAVE_CYCLES   9.63e+10  per_ns=883\n"
+            "== pass fetch: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false>: n=8 total_ms=109.0 vgpr=124/0\n"
+            "    FETCH_SIZE       3.7e+05  per_ns=3.4\n"
+            "== pass write: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false>: n=8 total_ms=109.0 vgpr=124/0\n"
+            "    WRITE_SIZE       2.048e+06  per_ns=18.8\n")
+    good = tmp_path / "r99_pmc_summary.txt"
+    good.write_text(f"# source_hash {bench.kernel_source_hash()}\n" + body)
+    t, note = bench.pmc_traffic_per_launch(summary=str(good))
+    assert abs(t - (2 * 3.7e5 + 2.048e6) * 1024 / 8) < 1 and "same kernel sources" in note
+    stale = tmp_path / "r98_pmc_summary.txt"
+    stale.write_text("# source_hash 0123abcd\n" + body)
+    t, note = bench.pmc_traffic_per_launch(summary=str(stale))
+    assert t is None and "other kernel sources" in note
+    unkeyed = tmp_path / "r97_pmc_summary.txt"
+    unkeyed.write_text(body)
+    assert bench.pmc_traffic_per_launch(summary=str(unkeyed))[0] is None
+    assert bench.pmc_traffic_per_launch("no_such_kernel", summary=str(good))[0] is None
+    # whatever is committed under profiles/ either matches this tree or is declined with a reason
+    t, note = bench.pmc_traffic_per_launch()
+    assert (t is None and note) or 0.75 < t / (16777216 * 20) < 1.25
