@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=16384, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=20, help="timed optimisation steps of the training leg (0 = skip)")
     ap.add_argument("--n-rand", type=int, default=4096, help="rays per GPU per optimisation step")
+    ap.add_argument("--strong-leg", type=int, default=1, help="0 = skip the 800x800 sharded view (only allowed with --mode weak)")
     ap.add_argument("--mode", choices=("weak", "strong"), default="weak",
                     help="headline: weak = every rank renders its own --rays batch; strong = one 800x800 view sharded over the ranks")
     a = ap.parse_args()
@@ -291,7 +292,7 @@ def main():
     train = None
     if a.train_steps > 0:
         train = train_leg(a, kw_train, models, dev, rank, world, fence)
-    strong = strong_leg(a, kw_test, dev, rank, world, fence)
+    strong = strong_leg(a, kw_test, dev, rank, world, fence) if (a.strong_leg or a.mode == "strong") else None
 
     mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
     mlp_points = sum(p for _, _, p in timing)

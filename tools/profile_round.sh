@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$ROUND
 rm -rf $O && mkdir -p $O
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-rays 0 > $O/bench_under_rocprof.json 2> $O/stats.err
-B="python3 $R/bench.py --steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --rays 262144"
+B="python3 $R/bench.py --steps 1 --warmup 1 --cpu-rays 0 --train-steps 3 --rays 262144 --strong-leg 0"
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.out 2>&1
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.out 2>&1
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.out 2>&1
