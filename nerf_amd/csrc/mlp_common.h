@@ -164,7 +164,7 @@ DEV void glds16_untracked_sbase(const void* base, unsigned lane_off, unsigned ld
 // (nothing is loaded for them, nothing reads them).
 template <int NCHUNKS, int RING, int DEPTH, int NLOAD = NCHUNKS, bool WRAP = false, int WAVES = kWavesPerBlock>
 struct Stream {
-    static_assert(WAVES == 8 || WAVES == 16, "a chunk is 16 KiB: 2 or 1 KiB per wave");
+    static_assert(WAVES == 4 || WAVES == 8 || WAVES == 16, "a chunk is 16 KiB: 4, 2 or 1 KiB per wave");
     static constexpr int kLoadsPerWave = kFragsPerChunk / WAVES;  // 1 KiB loads of one wave per chunk
     static_assert(DEPTH <= RING - 2 && kPrefetch <= 8, "ring slack");
     static_assert(!WRAP || NCHUNKS % RING == 0, "a wrapping stream keeps its slot phase");
@@ -195,13 +195,23 @@ struct Stream {
         rd_hi = (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)hi;
     }
 
+#ifdef EXP_STALE_RING  // timing experiment: loads only while `live` (later passes read stale ring data)
+    bool live = true;
+#endif
     template <int C>
     DEV void issue() {
         if constexpr (C < NLOAD) {
             const char* g = gsrc + (size_t)C * kChunkBytes;
             const unsigned l = wr + (C % RING) * kChunkBytes;
-            glds16_untracked_sbase(g, (unsigned)lane_off, l);
-            if constexpr (kLoadsPerWave == 2) glds16_untracked_sbase(g + kFragBytes, (unsigned)lane_off, l + kFragBytes);
+#ifdef EXP_STALE_RING
+            if (live)
+#endif
+            {
+                static_for<0, kLoadsPerWave>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    glds16_untracked_sbase(g + i * kFragBytes, (unsigned)lane_off, l + i * kFragBytes);
+                });
+            }
             vm.issued += kLoadsPerWave;
         }
         mark[C % RING] = vm.issued;
@@ -267,7 +277,9 @@ struct Stream {
         const half8 cur = a[F % kPrefetch];
         if constexpr ((F + 8) % kFragsPerChunk == 0 && (F + 8) / kFragsPerChunk < NCHUNKS)
             sync<(F + 8) / kFragsPerChunk>();
+#ifndef EXP_NO_LDS_READ  // timing experiment: the first kPrefetch fragments are used over and over
         if constexpr (F + kPrefetch < NCHUNKS * kFragsPerChunk) a[F % kPrefetch] = read<F + kPrefetch>();
+#endif
         return cur;
     }
 };

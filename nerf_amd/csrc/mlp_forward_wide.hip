@@ -25,6 +25,12 @@
 #include "mlp_common.h"
 #include "mlp_layout_wide.h"
 
+#ifdef FWD_STAMPS  // diagnostic build: shader-clock stamps at the layer boundaries of one pass
+#define LSTAMP(i) (lstamp[i] = __builtin_amdgcn_s_memtime())
+#else
+#define LSTAMP(i) ((void)0)
+#endif
+
 namespace nerf {
 
 struct FwdWideArgs {
@@ -39,6 +45,9 @@ struct FwdWideArgs {
     int64_t M;              // points = n_rays * S
     int64_t n_rays;
     int S;                  // points per ray
+#ifdef FWD_STAMPS  // diagnostic build only: per-workgroup shader-clock and wall-clock stamps
+    unsigned long long* stamps;  // [workgroups][4]: s_memtime begin/end, s_memrealtime begin/end
+#endif
 };
 
 // The ring: 5 slots of 16 KiB, 3 chunks in flight (measured equal to 8 / 6).  The 74 chunks of a
@@ -57,16 +66,22 @@ constexpr int kWRingBytes = WideStreamT<8>::kRingBytes;
 #ifndef NERF_FWD_WAVES
 #define NERF_FWD_WAVES 8
 #endif
+// 16-point tiles per wave of the inference kernel (every A fragment read from LDS feeds one MFMA
+// per point tile; the weight stream is read once per WAVES x 16 x NPT points).
+#ifndef NERF_FWD_NPT
+#define NERF_FWD_NPT 3
+#endif
 
 DEV f32x4 mfma_wide(half8 a, half8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <class STREAM>
+template <class STREAM, int NPT>
 struct WidePipe {
+    static constexpr int kNpt = NPT;  // 16-point tiles per wave
     STREAM& st;
     const char* bias;   // bias table in LDS, already offset by this lane group's 16 bytes
-    f32x4 acc[2][2];    // [tile parity][point tile]
+    f32x4 acc[2][NPT];  // [tile parity][point tile]
 };
 
 // Where a training forward saves its fragments: [wave tile][block][lane] (inference: unused).
@@ -109,11 +124,11 @@ struct FragLoad {
     }
 };
 
-// What happens to a finished pair of accumulators (one output tile, both point tiles): four
-// slices, each two registers of one point tile -> one packed dword.
+// What happens to the finished accumulators of one output tile (every point tile of the wave):
+// two slices per point tile, each two registers -> one packed dword.
 struct WNoPrev {
     static constexpr bool kActive = false;
-    template <int S> DEV void slice(const f32x4 (&)[2]) const {}
+    template <int S, class ACC> DEV void slice(const ACC&) const {}
 };
 // Tile number TL inside its layer (of NT): tiles 2s, 2s+1 fill the low / high half of fragment s.
 // STORE: a finished fragment s of point tile pt is saved as block ABLK + 2s + pt, and for
@@ -124,11 +139,11 @@ struct WNoPrev {
 template <bool RELU, int TL, bool STORE = false, int ABLK = 0, int MBLK = -1, int NT = 0>
 struct WToFrag {
     static constexpr bool kActive = true;
-    half8* dst0;  // fragment array of point tile 0, point tile 1 follows at +kStride
+    half8* dst0;  // fragment array of point tile 0, point tile pt follows at + pt * kStride
     WSink sink;
     unsigned* mk;
     static constexpr int kStride = 8;
-    template <int S> DEV void slice(const f32x4 (&v)[2]) const {
+    template <int S, class ACC> DEV void slice(const ACC& v) const {
         constexpr int pt = S >> 1, q = S & 1;
         half2v p;
         if constexpr (RELU) {
@@ -144,6 +159,11 @@ struct WToFrag {
         } else {
             const f32x2 x = {v[pt][2 * q], v[pt][2 * q + 1]};
             p = __builtin_convertvector(x, half2v);  // saturating
+            // the conversion stays in its slot (left free, the compiler sinks it to the fragment's
+            // first use and keeps the fp32 accumulators alive until then)
+            unsigned r = __builtin_bit_cast(unsigned, p);
+            asm volatile("" : "+v"(r));
+            p = __builtin_bit_cast(half2v, r);
         }
         half8& f = dst0[pt * kStride + (TL >> 1)];
         constexpr int e = 4 * (TL & 1) + 2 * q;
@@ -166,17 +186,27 @@ struct WToFrag {
 };
 struct WKeepRow0 {
     static constexpr bool kActive = true;
-    float* out;  // [2]
-    template <int S> DEV void slice(const f32x4 (&v)[2]) const {
+    float* out;  // [point tiles]
+    template <int S, class ACC> DEV void slice(const ACC& v) const {
         if constexpr ((S & 1) == 0) out[S >> 1] = v[S >> 1][0];
     }
 };
 
+// The 2 npt slices of a finished tile are spread evenly over the k-steps of the next one, from the
+// second k-step to the last but one: the first tile of a layer reads the fragment that the last
+// tile of the layer before completes in its LAST k-step (two-step tiles only ever follow a tile
+// of their own layer and take every slice in their second step).
 constexpr int w_first_slice_step(int nk) { return nk >= 2 ? 1 : 0; }
-constexpr int w_slices_per_step(int nk) { return nk >= 8 ? 1 : nk >= 4 ? 2 : 4; }
-constexpr int w_last_slice_step(int nk) { return w_first_slice_step(nk) + 3 / w_slices_per_step(nk); }
-constexpr int w_bias_step(int nk) { return w_last_slice_step(nk) > nk - 3 ? w_last_slice_step(nk) : nk - 3; }
-static_assert(w_last_slice_step(2) < 2 && w_last_slice_step(4) < 4 && w_last_slice_step(8) < 8, "slice schedule");
+constexpr int w_slices_per_step(int nk, int npt) {
+    const int steps = nk >= 3 ? nk - 2 : 1;
+    return (2 * npt + steps - 1) / steps;
+}
+constexpr int w_last_slice_step(int nk, int npt) { return w_first_slice_step(nk) + (2 * npt - 1) / w_slices_per_step(nk, npt); }
+constexpr int w_bias_step(int nk, int npt) { return w_last_slice_step(nk, npt) > nk - 3 ? w_last_slice_step(nk, npt) : nk - 3; }
+static_assert(w_slices_per_step(2, 2) == 4 && w_slices_per_step(4, 2) == 2 && w_slices_per_step(8, 2) == 1 &&
+              w_slices_per_step(9, 2) == 1 && w_slices_per_step(10, 2) == 1, "two point tiles: the schedule the training forward was tuned on");
+static_assert(w_last_slice_step(2, 3) < 2 && w_last_slice_step(4, 3) < 3 && w_last_slice_step(8, 3) < 7 &&
+              w_last_slice_step(9, 3) < 8 && w_last_slice_step(10, 3) < 9 && w_last_slice_step(4, 2) < 3, "slice schedule");
 
 // Output tile T (= its bias tile): NK k-steps of fragments F0..; getB(pt, k) is the B fragment of
 // point tile pt.  Every k-step is one scheduling region: two MFMAs, the LDS read of the A
@@ -186,18 +216,20 @@ template <int F0, int NK, int T, class PIPE, class GetB, class Prev>
 DEV void wide_tile(PIPE& p, GetB&& getB, const Prev& prev) {
     static_for<0, NK>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
+        constexpr int NPT = PIPE::kNpt, NS = 2 * NPT;
         const half8 a = p.st.template take<F0 + k>();
-        p.acc[T & 1][0] = mfma_wide(a, getB(std::integral_constant<int, 0>{}, kc), p.acc[T & 1][0]);
-        p.acc[T & 1][1] = mfma_wide(a, getB(std::integral_constant<int, 1>{}, kc), p.acc[T & 1][1]);
+        static_for<0, NPT>([&](auto ptc) {
+            constexpr int pt = decltype(ptc)::value;
+            p.acc[T & 1][pt] = mfma_wide(a, getB(ptc, kc), p.acc[T & 1][pt]);
+        });
         if constexpr (Prev::kActive && k >= w_first_slice_step(NK)) {
-            constexpr int sp = w_slices_per_step(NK), s0 = (k - w_first_slice_step(NK)) * sp;
-            static_for<(s0 < 4 ? s0 : 4), (s0 + sp < 4 ? s0 + sp : 4)>(
+            constexpr int sp = w_slices_per_step(NK, NPT), s0 = (k - w_first_slice_step(NK)) * sp;
+            static_for<(s0 < NS ? s0 : NS), (s0 + sp < NS ? s0 + sp : NS)>(
                 [&](auto sc) { prev.template slice<decltype(sc)::value>(p.acc[(T & 1) ^ 1]); });
         }
-        if constexpr (k == w_bias_step(NK) && T + 1 < lw::T_END) {
+        if constexpr (k == w_bias_step(NK, NPT) && T + 1 < lw::T_END) {
             const f32x4 b = *(const f32x4*)(p.bias + (T + 1) * 64);
-            p.acc[(T & 1) ^ 1][0] = b;
-            p.acc[(T & 1) ^ 1][1] = b;
+            static_for<0, NPT>([&](auto ptc) { p.acc[(T & 1) ^ 1][decltype(ptc)::value] = b; });
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -271,15 +303,15 @@ struct PointWords {
 };
 
 // Which ray a point belongs to, without a division per tile.  The first point of this wave in a
-// tile is base = tile * 256 + wave * 32 = q * S + r; the workgroup's next tile lies gridDim.x * 256
-// points further, which advances (q, r) by a fixed (dq, dr).  All of it is wave-uniform and runs
-// on the scalar unit; a lane adds its point number (< 32) to r and carries at most once when
-// S >= 32 (shorter rays take the division).
+// tile is base = tile * PB + wave * PW = q * S + r (PW points per wave, PB per workgroup tile); the
+// workgroup's next tile lies gridDim.x * PB points further, which advances (q, r) by a fixed
+// (dq, dr).  All of it is wave-uniform and runs on the scalar unit; a lane adds its point number
+// (< PW) to r and carries at most once when S >= PW (shorter rays take the division).
 struct RayCursor {
     int64_t base, q, dq, step;
-    int r, dr, S;
-    DEV RayCursor(int64_t tile, int wave, int S_, int points_per_block) : S(S_) {
-        base = tile * points_per_block + wave * kPointsPerWave;
+    int r, dr, S, pw;
+    DEV RayCursor(int64_t tile, int wave, int S_, int points_per_block, int points_per_wave) : S(S_), pw(points_per_wave) {
+        base = tile * points_per_block + wave * points_per_wave;
         q = base / S, r = (int)(base - q * S);
         step = (int64_t)gridDim.x * points_per_block;
         dq = step / S, dr = (int)(step - dq * S);
@@ -288,7 +320,7 @@ struct RayCursor {
         base += step, q += dq, r += dr;
         if (r >= S) r -= S, ++q;
     }
-    DEV int64_t ray_of(int l) const { return S >= kPointsPerWave ? q + (r + l >= S ? 1 : 0) : (base + l) / S; }
+    DEV int64_t ray_of(int l) const { return S >= pw ? q + (r + l >= S ? 1 : 0) : (base + l) / S; }
 };
 
 template <int MODE>
@@ -365,16 +397,25 @@ DEV void point_xyz(const PointWords& w, float (&x)[3], float (&vd)[3]) {
     }
 }
 
-template <int MODE, bool STORE, int WAVES>
+template <int MODE, bool STORE, int WAVES, int NPT>
 __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[kWRingBytes + lw::kBiasBytes];
-    constexpr int kPB = WAVES * kPointsPerWave;  // points per workgroup tile
+    // Three and more point tiles per wave: the point encoding waits in LDS (each wave its own
+    // 2 NPT KiB) between layer 0 and layer 5 instead of in 8 NPT registers.
+    constexpr bool kEncLds = NPT >= 3;
+    constexpr int kEncBytes = kEncLds ? WAVES * 2 * NPT * kFragBytes : 0;
+    __shared__ __attribute__((aligned(16))) char lds[kWRingBytes + lw::kBiasBytes + kEncBytes];
+    static_assert(!STORE || (NPT == 2 && WAVES == kWavesPerBlock), "saved activations are laid out in 32-point wave tiles, 8 per workgroup tile");
+    constexpr int kPW = 16 * NPT;      // points per wave
+    constexpr int kPB = WAVES * kPW;   // points per workgroup tile
     using WideStream = WideStreamT<WAVES>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
     const int64_t ntiles = (a.M + kPB - 1) / kPB;
     saturate_fp16_conversions();
+#ifdef FWD_STAMPS
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     VmQueue vm;
     WideStream st(vm, a.packed, lds, wave, lane);
@@ -385,7 +426,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
     st.prologue();
 
     constexpr int kS = 8;  // fragments (k-steps of 32 features) per point tile in a set
-    half8 fa[2 * kS], fb[2 * kS], pe[2][2], vpe[2][1];
+    half8 fa[NPT * kS], fb[NPT * kS], pe[NPT][2], vpe[NPT][1];
     auto from_pe = [&](auto pt, auto kc) { return pe[decltype(pt)::value][decltype(kc)::value]; };
     auto from_a = [&](auto pt, auto kc) { return fa[decltype(pt)::value * kS + decltype(kc)::value]; };
     auto from_b = [&](auto pt, auto kc) { return fb[decltype(pt)::value * kS + decltype(kc)::value]; };
@@ -395,20 +436,46 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
     // read is this register + an immediate (the table lies beyond a ds_read's 16-bit offset)
     unsigned bias_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + kWRingBytes + g * 16);
     asm volatile("" : "+v"(bias_addr));
-    WidePipe<WideStream> pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}};
+    WidePipe<WideStream, NPT> pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}};
 
     // ---- this lane's two query points (one per point tile) of the workgroup's first tile ----
-    RayCursor where(blockIdx.x, wave, a.S, kPB);
-    PointWords cur[2] = {load_point<MODE>(a, where, lane, 0), load_point<MODE>(a, where, lane, 1)};
-
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        st.rebase();
+    RayCursor where(blockIdx.x, wave, a.S, kPB, kPW);
+    PointWords cur[NPT];
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+    for (int pt = 0; pt < NPT; ++pt) cur[pt] = load_point<MODE>(a, where, lane, pt);
+
+#ifdef FWD_STAMPS
+    int pass_no = 0;
+#endif
+    // The lane number as a value the compiler cannot connect with its earlier uses: what a pass
+    // derives from it (lane group, point offsets, store addresses) is formed again where it is
+    // needed (one or two instructions) instead of being carried, or spilled, through the network.
+    auto fresh_lane = [&]() {
+        int off = st.lane_off;
+        asm volatile("" : "+v"(off));
+        return off >> 4;
+    };
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef FWD_STAMPS
+        unsigned long long lstamp[16];
+#endif
+        LSTAMP(0);
+        st.rebase();
+        const int lane_top = fresh_lane();
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
             float x[3], vd[3];
             point_xyz<MODE>(cur[pt], x, vd);
-            encode_point(x, g, pe[pt]);
-            encode_view(vd, g, vpe[pt]);
+            encode_point(x, lane_top >> 4, pe[pt]);
+            encode_view(vd, lane_top >> 4, vpe[pt]);
+        }
+        char* const enc_lds = lds + kWRingBytes + lw::kBiasBytes + wave * (2 * NPT * kFragBytes) + lane_top * 16;
+        if constexpr (kEncLds) {
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                *(half8*)(enc_lds + (2 * pt) * kFragBytes) = pe[pt][0];
+                *(half8*)(enc_lds + (2 * pt + 1) * kFragBytes) = pe[pt][1];
+            }
         }
 
         WSink sink{nullptr, &vm};
@@ -427,90 +494,139 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
         }
         const int enc_saved = vm.issued;  // the saved encodings are in memory once the queue is past this mark
         FragLoad lpe[4], lvpe[2];
-        PointFetch nxt[2];
+        PointFetch nxt[NPT];
         unsigned mk[4] = {0u, 0u, 0u, 0u};
 
+        LSTAMP(1);
         st.start();
+        LSTAMP(2);
         {
             const f32x4 b = *(const f32x4*)(pp.bias);
-            pp.acc[0][0] = b, pp.acc[0][1] = b;
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) pp.acc[0][pt] = b;
         }
         auto c0 = wide_layer<lw::F_L0, 16, 2, lw::T_L0, true, STORE, A_H0, A_MASK + 0>(pp, sink, mk, fa, from_pe, WNoPrev{});                     // layer 0
+        LSTAMP(3);
         auto c1 = wide_layer<lw::F_L1 + 0 * 128, 16, 8, lw::T_L1 + 0, true, STORE, A_H0 + 16, A_MASK + 1>(pp, sink, mk, fb, from_a, c0);        // layers 1..4
+        LSTAMP(4);
         auto c2 = wide_layer<lw::F_L1 + 1 * 128, 16, 8, lw::T_L1 + 16, true, STORE, A_H0 + 32, A_MASK + 2>(pp, sink, mk, fa, from_b, c1);
+        LSTAMP(5);
         auto c3 = wide_layer<lw::F_L1 + 2 * 128, 16, 8, lw::T_L1 + 32, true, STORE, A_H0 + 48, A_MASK + 3>(pp, sink, mk, fb, from_a, c2);
+        LSTAMP(6);
         if constexpr (STORE) {  // the point encoding comes back during layer 4 (blocks A_PE + 2k + pt)
             vm.wait_until(enc_saved);
             static_for<0, 4>([&](auto ic) { lpe[decltype(ic)::value].issue(vm, act_tile + (A_PE + decltype(ic)::value) * kFragBytes, lane * 16); });
         }
         auto c4 = wide_layer<lw::F_L1 + 3 * 128, 16, 8, lw::T_L1 + 48, true, STORE, A_H0 + 64, A_MASK + 4>(pp, sink, mk, fa, from_b, c3);
-        half8 pe5[2][2];
-        static_for<0, 4>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, k = i >> 1, pt = i & 1;
-            if constexpr (STORE) pe5[pt][k] = lpe[i].get(vm); else pe5[pt][k] = pe[pt][k];
+        LSTAMP(7);
+        half8 pe5[NPT][2];
+        static_for<0, 2 * NPT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, k = i / NPT, pt = i % NPT;  // STORE (NPT = 2): block A_PE + 2 k + pt
+            if constexpr (STORE) pe5[pt][k] = lpe[i].get(vm);
+            else if constexpr (!kEncLds) pe5[pt][k] = pe[pt][k];
         });
         auto c5 = wide_layer<lw::F_L5, 16, 10, lw::T_L5, true, STORE, A_H0 + 80, A_MASK + 5>(pp, sink, mk, fb, [&](auto pt, auto kc) {         // layer 5: [PE ; h]
             constexpr int k = decltype(kc)::value;
-            if constexpr (k < 2) return pe5[decltype(pt)::value][k]; else return fa[decltype(pt)::value * kS + k - 2];
+            if constexpr (k < 2 && kEncLds) return *(const half8*)(enc_lds + (2 * decltype(pt)::value + k) * kFragBytes);
+            else if constexpr (k < 2) return pe5[decltype(pt)::value][k];
+            else return fa[decltype(pt)::value * kS + k - 2];
         }, c4);
+        LSTAMP(8);
         auto c6 = wide_layer<lw::F_L6 + 0 * 128, 16, 8, lw::T_L6 + 0, true, STORE, A_H0 + 96, A_MASK + 6>(pp, sink, mk, fa, from_b, c5);        // layers 6, 7
+        LSTAMP(9);
         auto c7 = wide_layer<lw::F_L6 + 1 * 128, 16, 8, lw::T_L6 + 16, true, STORE, A_H0 + 112, A_MASK + 7>(pp, sink, mk, fb, from_a, c6);
+        LSTAMP(10);
         // alpha head (row 0 of its tile), then the bottleneck (linear)
-        float sigma[2];
+        float sigma[NPT];
         wide_tile<lw::F_ALPHA, 8, lw::T_ALPHA>(pp, from_b, c7);
         if constexpr (STORE) {  // the view encoding comes back during the bottleneck layer
             lvpe[0].issue(vm, act_tile + A_VPE * kFragBytes, lane * 16);
             lvpe[1].issue(vm, act_tile + (A_VPE + 1) * kFragBytes, lane * 16);
         }
         auto c8 = wide_layer<lw::F_BOTT, 16, 8, lw::T_BOTT, false, STORE, A_BOTT, -1>(pp, sink, mk, fa, from_b, WKeepRow0{sigma});
-        half8 vpe9[2];
-        if constexpr (STORE) vpe9[0] = lvpe[0].get(vm), vpe9[1] = lvpe[1].get(vm); else vpe9[0] = vpe[0][0], vpe9[1] = vpe[1][0];
+        LSTAMP(11);
+        half8 vpe9[NPT];
+        if constexpr (STORE) vpe9[0] = lvpe[0].get(vm), vpe9[1] = lvpe[1].get(vm);
+        else {
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) vpe9[pt] = vpe[pt][0];
+        }
         // the next tile's rays and depths are requested before the last two layers (past the
         // last tile the addresses are clamped to the last point and the words are not used)
         where.advance();
-        nxt[0].template issue<MODE>(vm, a, where, lane, 0);
-        nxt[1].template issue<MODE>(vm, a, where, lane, 1);
+        const int lane_nxt = fresh_lane();
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) nxt[pt].template issue<MODE>(vm, a, where, lane_nxt, pt);
         // view layer: [bottleneck ; view PE] -> 128, relu
         auto c9 = wide_layer<lw::F_VIEW, 8, 9, lw::T_VIEW, true, STORE, A_V, A_MASK + 8>(pp, sink, mk, fb, [&](auto pt, auto kc) {
             constexpr int k = decltype(kc)::value;
             if constexpr (k < 8) return fa[decltype(pt)::value * kS + k]; else return vpe9[decltype(pt)::value];
         }, c8);
+        LSTAMP(12);
         wide_tile<lw::F_RGB, 4, lw::T_RGB>(pp, from_b, c9);                                                  // rgb rows 0..2
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+        for (int pt = 0; pt < NPT; ++pt) {
             const f32x4& c = pp.acc[lw::T_RGB & 1][pt];
-            // the lane id is read afresh: neither it nor the point index is worth registers through the network
-            const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            const int64_t p = tile * kPB + wave * kPointsPerWave + 16 * pt + (ln & 15);
+            const int ln = fresh_lane();
+            const int64_t p = tile * kPB + wave * kPW + 16 * pt + (ln & 15);
             if (p < a.M && (ln >> 4) == 0) a.raw[p] = make_float4(c[0], c[1], c[2], sigma[pt]);
         }
+        LSTAMP(13);
+#ifdef EXP_STALE_RING
+        st.live = false;
+#endif
         st.finish_pass();
-        cur[0] = nxt[0].get(vm), cur[1] = nxt[1].get(vm);
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) cur[pt] = nxt[pt].get(vm);
+        LSTAMP(14);
+#ifdef FWD_STAMPS
+        if (++pass_no == 6 && a.stamps && lane == 0 && blockIdx.x < 32) {
+            unsigned long long* o = a.stamps + 4 * 256 + ((size_t)blockIdx.x * WAVES + wave) * 16;
+#pragma unroll
+            for (int i = 0; i < 15; ++i) o[i] = lstamp[i];
+        }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring loads requested for a pass that does not come
+#ifdef FWD_STAMPS
+    if (threadIdx.x == 0 && a.stamps) {
+        unsigned long long* s = a.stamps + 4 * (size_t)blockIdx.x;
+        s[0] = stamp_c0, s[1] = __builtin_amdgcn_s_memtime(), s[2] = stamp_r0, s[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
-static int launch_fwd_wide(const FwdWideArgs& a, int mode, hipStream_t st, const char* what) {
-    constexpr int kInferWaves = NERF_FWD_WAVES;
-    const int64_t tiles = a.act ? (a.M + kPointsPerBlock - 1) / kPointsPerBlock
-                                : (a.M + kInferWaves * kPointsPerWave - 1) / (kInferWaves * kPointsPerWave);
+#ifdef FWD_STAMPS
+static unsigned long long* g_fwd_stamps = nullptr;
+#endif
+
+static int launch_fwd_wide(FwdWideArgs a, int mode, hipStream_t st, const char* what) {
+    constexpr int kInferWaves = NERF_FWD_WAVES, kInferNpt = NERF_FWD_NPT, kInferPB = kInferWaves * 16 * kInferNpt;
+    const int64_t tiles = a.act ? (a.M + kPointsPerBlock - 1) / kPointsPerBlock : (a.M + kInferPB - 1) / kInferPB;
     if (a.S > (1 << 24)) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: more than 2^24 points per ray (%d)", what, a.S);
     // persistent workgroups: one per CU (the ring and two waves per SIMD fill a CU), fewer for small calls
     const int cus = device_cu_count();
     if (cus <= 0) return NERF_FAIL(NERF_E_UNSUPPORTED, "%s: no current device", what);
     const int64_t blocks = tiles < cus ? tiles : cus;
+#ifdef FWD_STAMPS
+    a.stamps = g_fwd_stamps;
+#endif
     if (a.act)
-        mlp_fwd_wide_kernel<0, true, kWavesPerBlock><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(a);
+        mlp_fwd_wide_kernel<0, true, kWavesPerBlock, 2><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(a);
     else if (mode == 0)
-        mlp_fwd_wide_kernel<0, false, kInferWaves><<<(unsigned)blocks, kInferWaves * 64, 0, st>>>(a);
+        mlp_fwd_wide_kernel<0, false, kInferWaves, kInferNpt><<<(unsigned)blocks, kInferWaves * 64, 0, st>>>(a);
     else
-        mlp_fwd_wide_kernel<1, false, kInferWaves><<<(unsigned)blocks, kInferWaves * 64, 0, st>>>(a);
+        mlp_fwd_wide_kernel<1, false, kInferWaves, kInferNpt><<<(unsigned)blocks, kInferWaves * 64, 0, st>>>(a);
     return check_launch(what);
 }
 
 }  // namespace nerf
 
 using namespace nerf;
+
+#ifdef FWD_STAMPS
+NERF_API void nerf_debug_set_fwd_stamps(void* p) { g_fwd_stamps = (unsigned long long*)p; }
+#endif
 
 NERF_API int nerf_mlp_forward_rays(const void* packed, const float* rays, int width,
                                    const float* z, int64_t n_rays, int S, float* raw,
