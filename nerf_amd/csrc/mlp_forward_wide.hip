@@ -238,14 +238,16 @@ DEV void wide_tile(PIPE& p, GetB&& getB, const Prev& prev) {
 // One layer of NT output tiles of NK k-steps; its output becomes fragments 0..NT/2-1 of `out`
 // (both point tiles).  `before` finishes the tile that preceded the layer; the returned object
 // finishes the layer's last tile.
-template <int F0, int NT, int NK, int T0, bool RELU, bool STORE, int ABLK, int MBLK, class PIPE, class GetB, class Prev>
+// TB, TE: only tiles TB .. TE-1 of the layer (a layer may be run in two parts whose B operands
+// come from different places).
+template <int F0, int NT, int NK, int T0, bool RELU, bool STORE, int ABLK, int MBLK, int TB = 0, int TE = NT, class PIPE, class GetB, class Prev>
 DEV auto wide_layer(PIPE& p, const WSink& sink, unsigned* mk, half8* out, GetB&& getB, const Prev& before) {
-    wide_tile<F0, NK, T0>(p, getB, before);
-    static_for<1, NT>([&](auto tc) {
+    wide_tile<F0 + TB * NK, NK, T0 + TB>(p, getB, before);
+    static_for<TB + 1, TE>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         wide_tile<F0 + t * NK, NK, T0 + t>(p, getB, WToFrag<RELU, t - 1, STORE, ABLK, MBLK, NT>{out, sink, mk});
     });
-    return WToFrag<RELU, NT - 1, STORE, ABLK, MBLK, NT>{out, sink, mk};
+    return WToFrag<RELU, TE - 1, STORE, ABLK, MBLK, NT>{out, sink, mk};
 }
 
 // Local encoding slots of lane group g for a point: see lw::pe_feature.
@@ -400,9 +402,11 @@ DEV void point_xyz(const PointWords& w, float (&x)[3], float (&vd)[3]) {
 template <int MODE, bool STORE, int WAVES, int NPT>
 __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a) {
     // Three and more point tiles per wave: the point encoding waits in LDS (each wave its own
-    // 2 NPT KiB) between layer 0 and layer 5 instead of in 8 NPT registers.
+    // 2 NPT KiB) between layer 0 and layer 5 instead of in 8 NPT registers, and the view
+    // directions (16 B per point) wait there until the view layer, where they are encoded.
     constexpr bool kEncLds = NPT >= 3;
-    constexpr int kEncBytes = kEncLds ? WAVES * 2 * NPT * kFragBytes : 0;
+    constexpr int kEncWaveBytes = 2 * NPT * kFragBytes + NPT * 256;
+    constexpr int kEncBytes = kEncLds ? WAVES * kEncWaveBytes : 0;
     __shared__ __attribute__((aligned(16))) char lds[kWRingBytes + lw::kBiasBytes + kEncBytes];
     static_assert(!STORE || (NPT == 2 && WAVES == kWavesPerBlock), "saved activations are laid out in 32-point wave tiles, 8 per workgroup tile");
     constexpr int kPW = 16 * NPT;      // points per wave
@@ -467,9 +471,14 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
             float x[3], vd[3];
             point_xyz<MODE>(cur[pt], x, vd);
             encode_point(x, lane_top >> 4, pe[pt]);
-            encode_view(vd, lane_top >> 4, vpe[pt]);
+            if constexpr (kEncLds) {  // every lane group of a point writes the same 16 bytes
+                *(f32x4*)(lds + kWRingBytes + lw::kBiasBytes + wave * kEncWaveBytes + 2 * NPT * kFragBytes + pt * 256 + (lane_top & 15) * 16) =
+                    f32x4{vd[0], vd[1], vd[2], 0.f};
+            } else {
+                encode_view(vd, lane_top >> 4, vpe[pt]);
+            }
         }
-        char* const enc_lds = lds + kWRingBytes + lw::kBiasBytes + wave * (2 * NPT * kFragBytes) + lane_top * 16;
+        char* const enc_lds = lds + kWRingBytes + lw::kBiasBytes + wave * kEncWaveBytes + lane_top * 16;
         if constexpr (kEncLds) {
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) {
@@ -523,14 +532,26 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
         static_for<0, 2 * NPT>([&](auto ic) {
             constexpr int i = decltype(ic)::value, k = i / NPT, pt = i % NPT;  // STORE (NPT = 2): block A_PE + 2 k + pt
             if constexpr (STORE) pe5[pt][k] = lpe[i].get(vm);
-            else if constexpr (!kEncLds) pe5[pt][k] = pe[pt][k];
+            else if constexpr (kEncLds) pe5[pt][k] = *(const half8*)(enc_lds + (2 * pt + k) * kFragBytes);
+            else pe5[pt][k] = pe[pt][k];
         });
-        auto c5 = wide_layer<lw::F_L5, 16, 10, lw::T_L5, true, STORE, A_H0 + 80, A_MASK + 5>(pp, sink, mk, fb, [&](auto pt, auto kc) {         // layer 5: [PE ; h]
+        // layer 5: [PE ; h].  With the encoding parked in LDS it is held in registers only while the
+        // layer's output set has room to spare (its last two fragments per point tile are born in
+        // tiles 12..15); those last tiles read it from LDS again, k-step by k-step.
+        constexpr int kL5Split = kEncLds ? 12 : 16;
+        auto c5a = wide_layer<lw::F_L5, 16, 10, lw::T_L5, true, STORE, A_H0 + 80, A_MASK + 5, 0, kL5Split>(pp, sink, mk, fb, [&](auto pt, auto kc) {
             constexpr int k = decltype(kc)::value;
-            if constexpr (k < 2 && kEncLds) return *(const half8*)(enc_lds + (2 * decltype(pt)::value + k) * kFragBytes);
-            else if constexpr (k < 2) return pe5[decltype(pt)::value][k];
-            else return fa[decltype(pt)::value * kS + k - 2];
+            if constexpr (k < 2) return pe5[decltype(pt)::value][k]; else return fa[decltype(pt)::value * kS + k - 2];
         }, c4);
+        auto c5 = [&]() {
+            if constexpr (kEncLds)
+                return wide_layer<lw::F_L5, 16, 10, lw::T_L5, true, STORE, A_H0 + 80, A_MASK + 5, kL5Split, 16>(pp, sink, mk, fb, [&](auto pt, auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < 2) return *(const half8*)(enc_lds + (2 * decltype(pt)::value + k) * kFragBytes);
+                    else return fa[decltype(pt)::value * kS + k - 2];
+                }, c5a);
+            else return c5a;
+        }();
         LSTAMP(8);
         auto c6 = wide_layer<lw::F_L6 + 0 * 128, 16, 8, lw::T_L6 + 0, true, STORE, A_H0 + 96, A_MASK + 6>(pp, sink, mk, fa, from_b, c5);        // layers 6, 7
         LSTAMP(9);
@@ -548,8 +569,19 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
         half8 vpe9[NPT];
         if constexpr (STORE) vpe9[0] = lvpe[0].get(vm), vpe9[1] = lvpe[1].get(vm);
         else {
+            const int lane_view = fresh_lane();
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) vpe9[pt] = vpe[pt][0];
+            for (int pt = 0; pt < NPT; ++pt) {
+                if constexpr (kEncLds) {
+                    const f32x4 d = *(const f32x4*)(lds + kWRingBytes + lw::kBiasBytes + wave * kEncWaveBytes + 2 * NPT * kFragBytes + pt * 256 + (lane_view & 15) * 16);
+                    const float vd[3] = {d[0], d[1], d[2]};
+                    half8 e[1];
+                    encode_view(vd, lane_view >> 4, e);
+                    vpe9[pt] = e[0];
+                } else {
+                    vpe9[pt] = vpe[pt][0];
+                }
+            }
         }
         // the next tile's rays and depths are requested before the last two layers (past the
         // last tile the addresses are clamped to the last point and the words are not used)
