@@ -2,20 +2,31 @@
 // with the skip after layer 4 -> alpha / bottleneck / view layer / rgb, one kernel, activations
 // resident in registers from the first layer to the last (see mlp_layout_wide.h).
 //
-// Work decomposition.  A workgroup is 8 waves (2 per SIMD); each wave owns 32 query points (two
-// 16-point tiles) for the whole network, so a workgroup covers 256 points at a time.  Workgroups
-// are persistent (one per CU, tiles of 256 points dealt round-robin): while a tile's last layers
+// Work decomposition.  A workgroup is 8 waves (2 per SIMD); each wave owns NPT 16-point tiles for
+// the whole network: NPT = 3 for inference (48 points per wave, 384 per workgroup tile), NPT = 2
+// for the training forward (its saved activations are laid out in 32-point wave tiles).
+// Workgroups are persistent (one per CU, tiles dealt round-robin): while a tile's last layers
 // run, the weight stream already refills the ring for the next tile and the next tile's rays
-// and depths are fetched, so a CU never waits for a workgroup launch, a cold ring or its inputs
-// (with one workgroup per tile that cost 3.0 us from workgroup start to the first chunk + 2.2 us
-// between workgroups, of 52.6 us per tile).  A layer is computed
-// one 16-row output tile at a time: one A fragment per k-step feeds two v_mfma_f32_16x16x32_f16
-// (one per point tile), 2 x 4 fp32 accumulator registers seeded with the biases.  A finished tile
-// is converted (fp16 rounding, then a packed ReLU) in four slices placed between the MFMAs of the
-// FOLLOWING tile, so the matrix pipe never waits behind a block of conversion instructions; two
-// consecutive tiles make one B fragment of the next layer.  Two fragment sets ping-pong between
-// layers.  Live state per wave: 2 sets x 2 point tiles x 8 fragments x 4 registers + the
-// encodings (24) + accumulators (16) + the A-fragment pipeline.
+// and depths are fetched, so a CU never waits for a workgroup launch, a cold ring or its inputs.
+// A layer is computed one 16-row output tile at a time: one A fragment per k-step feeds NPT
+// v_mfma_f32_16x16x32_f16 (one per point tile), 2 x NPT x 4 fp32 accumulator registers seeded
+// with the biases.  A finished tile is converted (fp16 rounding, then a packed ReLU) in 2 NPT
+// slices placed between the MFMAs of the FOLLOWING tile, so the matrix pipe never waits behind a
+// block of conversion instructions; two consecutive tiles make one B fragment of the next layer.
+// Two fragment sets ping-pong between layers.
+//
+// Why three point tiles.  Under this kernel the chip is power-limited (in-kernel clock 1.8-1.95
+// of 2.4 GHz), and what costs power besides the MFMAs is operand delivery for the weights: the
+// L2 -> LDS stream (once per workgroup tile) and the LDS -> register fragment reads (once per
+// wave and k-step).  Measured by leaving each out (results wrong, timing only): no stream +17 %
+// (clock 1.77 -> 2.08 GHz), no fragment reads +12 %.  A third point tile divides both by 1.5 per
+// point and pays +6..7 % end to end with bit-identical results.  Its 96 more registers come from
+// parking what is not needed between layers in LDS: the point encoding (used by layers 0 and 5)
+// and the view directions (encoded only before the view layer); live state per wave is then
+// 2 sets x 3 point tiles x 8 fragments x 4 registers + accumulators (24) + the A-fragment pipeline
+// (16), 246 of the 256 registers two waves per SIMD allow, no spills.  (A spill would be a
+// disaster here, not a nuisance: the compiler waits for vmcnt(0) before using a reloaded
+// register, which drains the whole weight stream.)
 //
 // Weight stream: as in mlp_common.h (L2 -> LDS ring of 16 KiB chunks shared by the 8 waves,
 // counted waits, one barrier per chunk executed half a chunk early).
@@ -52,17 +63,17 @@ struct FwdWideArgs {
 
 // The ring: 5 slots of 16 KiB, 3 chunks in flight (measured equal to 8 / 6).  The 74 chunks of a
 // network count as 75 ring positions, a multiple of the slot count, so that a workgroup can run
-// the stream again for its next 256 points with the same compile-time slot of every chunk.
+// the stream again for its next tile with the same compile-time slot of every chunk.
 constexpr int kWRing = 5;
 constexpr int kWDepth = 3;
 constexpr int kWRingChunks = lw::kChunks + 1;
 template <int WAVES>
 using WideStreamT = Stream<kWRingChunks, kWRing, kWDepth, lw::kChunks, true, WAVES>;
 constexpr int kWRingBytes = WideStreamT<8>::kRingBytes;
-// Waves per workgroup of the inference kernel.  8 (two per SIMD): a wave's live state is 244
-// registers (two fragment sets of 2 x 8 x 4, encodings, accumulators, the A-fragment pipeline), so
-// 16 waves (four per SIMD, 128 registers each) spill 700 bytes per lane.  The training forward is
-// always 8 (its saved-activation buffer is sized in 256-point tiles).
+// Waves per workgroup of the inference kernel.  8 (two per SIMD): a wave's live state fills the 256
+// registers that leaves (see the head of the file); 16 waves (four per SIMD, 128 registers each)
+// spill even with two point tiles.  The training forward is always 8 (its saved-activation buffer
+// is sized in 256-point tiles).
 #ifndef NERF_FWD_WAVES
 #define NERF_FWD_WAVES 8
 #endif
