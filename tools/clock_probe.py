@@ -45,9 +45,9 @@ mfma_cyc_per_simd = pts/32/1024 * 2344*16   # tiles per CU x cycles per tile per
 print(f"launch {ms:.3f} ms = {tf:.1f} TFLOP/s; in-kernel clock median {np.median(clk):.3f} GHz (p10 {np.percentile(clk,10):.3f}, p90 {np.percentile(clk,90):.3f}); WG span median {np.median(span):.1f} us")
 print(f"MFMA pipe busy at that clock: {mfma_cyc_per_simd/(np.median(s[:,1]-s[:,0])):.3f}; finite raw: {bool(torch.isfinite(raw).all())}; mean rgb pre-act {raw[...,:3].mean().item():.3f}")
 
-names = ["rebase+PE","start(sync0)","bias0","L0","L1","L2","L3","L4","L5","L6","L7","alpha+bott","view","rgb+store","finish+next"]
+names = ["rebase+PE","start(sync0)","L0","L1","L2","L3","L4","L5","L6","L7","alpha+bott","view+fetch","rgb+store","finish"]
 d = np.diff(ls[:,:,:15],axis=2)  # [blk][wave][14]
-print("segment: median cycles over 32 WGs x 8 waves (ideal hidden layer = 8192 per SIMD pair, L0 2048, L5 10240, alpha+bott 8448, view 4608)")
+print("segment: median cycles over 32 WGs x 8 waves (MFMA-only time of a SIMD's two waves per point tile: hidden layer 4096, L0 1024, L5 5120, alpha+bott 4224, view 2304)")
 for i in range(14):
     print(f"  {names[i]:>14s}: {np.median(d[:,:,i]):8.0f}  (p10 {np.percentile(d[:,:,i],10):8.0f} p90 {np.percentile(d[:,:,i],90):8.0f})")
 tot = ls[:,:,14]-ls[:,:,0]
