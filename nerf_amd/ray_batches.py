@@ -63,8 +63,11 @@ class RayBatcher:
         self.use_batching = bool(use_batching)
         self.precrop_iters, self.precrop_frac = int(precrop_iters), float(precrop_frac)
         self.gen = torch.Generator(device=dev)
+        self.host_gen = torch.Generator()  # the image of a step is drawn on the host: no device round trip
         if seed is not None:
             self.gen.manual_seed(int(seed))
+            self.host_gen.manual_seed(int(seed) + 1)
+        self._window_ids = {}  # window -> its flat pixel ids, resident on the device
         self.n_rays = self.n_img * self.H * self.W
         self.perm = None
         self.i_batch = 0
@@ -91,9 +94,11 @@ class RayBatcher:
     # -- one image per step ------------------------------------------------------------------
     def _single(self, i, image=None, select=None):
         if image is None:
-            image = int(torch.randint(self.n_img, (1,), device=self.device, generator=self.gen).item())
+            image = int(torch.randint(self.n_img, (1,), generator=self.host_gen))
         window = precrop_window(self.H, self.W, self.precrop_frac) if i < self.precrop_iters else None
-        pix = torch.as_tensor(window_pixels(self.H, self.W, window), device=self.device)
+        pix = self._window_ids.get(window)
+        if pix is None:  # two windows at most: the central crop and the whole image
+            pix = self._window_ids[window] = torch.as_tensor(window_pixels(self.H, self.W, window), device=self.device)
         if select is None:
             select = torch.randperm(pix.numel(), device=self.device, generator=self.gen)[:self.N_rand]
         pix = pix[torch.as_tensor(select, device=self.device).to(torch.int64)]

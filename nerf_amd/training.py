@@ -17,6 +17,8 @@ torch.autograd.grad call; outside it everything takes the lean inference path.
 """
 import math
 
+import numpy as np
+
 import torch
 
 from . import _native as nv
@@ -203,6 +205,15 @@ class Adam:
         """Lets the optimiser tell the models that their parameters changed (re-pack on next use)."""
         self.owners = [m for m in models if hasattr(m, 'mark_dirty')]
         return self
+
+    def get_weights(self):
+        """Keras' optimizer.get_weights(): [iterations, m of every variable..., v of every variable...]
+        (one flat array per parameter buffer here), so that an optimiser stored in the models
+        dictionary can be checkpointed like a network."""
+        out = [np.asarray(self.iterations, dtype=np.int64)]
+        for key in ('m', 'v'):
+            out += [g[key].detach().cpu().numpy() for g in (self._groups or [])]
+        return out
 
     def _lr(self):
         lr = self.learning_rate

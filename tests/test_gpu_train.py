@@ -268,6 +268,17 @@ def test_mse_and_keras_adam(gpu):
         th, m, v = orc.keras_adam_step(th, g.astype(np.float64), m, v, it, orc.lr_schedule(5e-4, 250, it))
     assert opt.iterations == 5
     np.testing.assert_allclose(flat.cpu().numpy(), th, rtol=2e-6, atol=2e-7)
+    # the optimiser state in Keras' get_weights() order, so that an optimiser kept in the models
+    # dictionary goes through the same checkpoint writer as a network (run_nerf.py:838-842)
+    ws = opt.get_weights()
+    assert int(ws[0]) == 5 and len(ws) == 3
+    np.testing.assert_allclose(ws[1], m, rtol=2e-5, atol=1e-6 * np.abs(m).max())   # fp32 sums of mixed signs
+    np.testing.assert_allclose(ws[2], v, rtol=2e-5, atol=1e-6 * np.abs(v).max())
+    import tempfile
+    from nerf_amd import checkpoint
+    with tempfile.TemporaryDirectory() as d:
+        back = np.load(checkpoint.save_weights(opt, 'optimizer', 5, d, 'exp'), allow_pickle=True)
+        assert len(back) == 3 and int(back[0]) == 5
 
 
 @pytest.mark.parametrize("n", [96, 4096])

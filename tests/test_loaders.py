@@ -65,6 +65,47 @@ def test_png_reader_rejects_garbage(tmp_path):
     p.write_bytes(b"not a png at all")
     with pytest.raises(ValueError):
         imageio_lite.imread(str(p))
+    p.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)   # a JPEG header (image_extn = .jpg configs)
+    with pytest.raises(ValueError, match="JPEG"):
+        imageio_lite.imread(str(p))
+
+
+def _write_png16(path, img, filters):
+    """16-bit samples, big-endian, filtered byte-wise with a step of 2 bytes per channel."""
+    h, w = img.shape
+    be = img.astype(">u2").view(np.uint8).reshape(h, w * 2).astype(np.int64)
+    bpp, raw = 2, bytearray()
+    for y in range(h):
+        f = filters[y % len(filters)]
+        raw.append(f)
+        for x in range(w * 2):
+            a = be[y, x - bpp] if x >= bpp else 0
+            b = be[y - 1, x] if y else 0
+            cc = be[y - 1, x - bpp] if (y and x >= bpp) else 0
+            raw.append(int(be[y, x] - [0, a, b, (a + b) // 2, _paeth(a, b, cc)][f]) & 0xff)
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as fp:
+        fp.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0))
+                 + chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("filters", [[0], [0, 1, 2, 3, 4]])
+def test_png_reader_16_bit_depth_maps(tmp_path, filters):
+    """load_blender.py:112-121 reads Kinect depth maps as 16-bit PNGs whose invalid readings are
+    0 and 65535; smooth_kinect_depth fills them with the nearest valid one."""
+    from nerf_amd.load_blender import smooth_kinect_depth
+    rng = np.random.default_rng(5)
+    depth = rng.integers(400, 3000, size=(9, 11)).astype(np.uint16)
+    depth[2, 3], depth[7, 1] = 0, 65535
+    p = str(tmp_path / "d.png")
+    _write_png16(p, depth, filters)
+    got = imageio_lite.imread(p)
+    assert got.dtype == np.uint16
+    np.testing.assert_array_equal(got, depth)
+    smooth = smooth_kinect_depth(got)
+    assert smooth.dtype == np.float32 and smooth.min() >= 0.4 and smooth.max() < 3.0
+    np.testing.assert_allclose(smooth[0, 0], depth[0, 0] / 1000., rtol=1e-6)
 
 
 # ---- option reader ------------------------------------------------------------------------------
