@@ -52,7 +52,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def pmc_traffic_per_launch(kernel="mlp_fwd_wide_kernel<0, false>", summary=None):
+def pmc_traffic_per_launch(kernel="mlp_fwd_wide_kernel<0, false,", summary=None):
     """(HBM bytes per launch of the dominant kernel, note) from the newest committed rocprofv3
     counter summary (profiles/rNN_pmc_summary.txt, written by tools/profile_round.sh: FETCH_SIZE and
     WRITE_SIZE in KiB summed over n dispatches of the same launch shapes as the default bench --

@@ -212,11 +212,11 @@ def test_bench_quotes_counter_traffic_only_for_matching_kernel_sources(tmp_path)
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    body = ("== pass sq: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false>: n=8 total_ms=109.0 vgpr=124/0\n"
+    body = ("== pass sq: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false, 8, 3>: n=8 total_ms=109.0 vgpr=124/0\n"
             "    SQ_WAVE_CYCLES   9.63e+10  per_ns=883\n"
-            "== pass fetch: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false>: n=8 total_ms=109.0 vgpr=124/0\n"
+            "== pass fetch: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false, 8, 3>: n=8 total_ms=109.0 vgpr=124/0\n"
             "    FETCH_SIZE       3.7e+05  per_ns=3.4\n"
-            "== pass write: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false>: n=8 total_ms=109.0 vgpr=124/0\n"
+            "== pass write: cmd\nvoid nerf::mlp_fwd_wide_kernel<0, false, 8, 3>: n=8 total_ms=109.0 vgpr=124/0\n"
             "    WRITE_SIZE       2.048e+06  per_ns=18.8\n")
     good = tmp_path / "r99_pmc_summary.txt"
     good.write_text(f"# source_hash {bench.kernel_source_hash()}\n" + body)
