@@ -2,6 +2,7 @@
 persistent workgroup, after >= 2 s of back-to-back launches on random data."""
 import ctypes, sys, time, torch, numpy as np
 L = ctypes.CDLL(sys.argv[1])
+NPT = int(sys.argv[2]) if len(sys.argv) > 2 else 3   # point tiles per wave of the build under test
 L.nerf_mlp_forward_rays.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 L.nerf_mlp_packed_bytes.restype = ctypes.c_size_t
 L.nerf_mlp_pack.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -47,9 +48,9 @@ print(f"MFMA pipe busy at that clock: {mfma_cyc_per_simd/(np.median(s[:,1]-s[:,0
 
 names = ["rebase+PE","start(sync0)","L0","L1","L2","L3","L4","L5","L6","L7","alpha+bott","view+fetch","rgb+store","finish"]
 d = np.diff(ls[:,:,:15],axis=2)  # [blk][wave][14]
-print("segment: median cycles over 32 WGs x 8 waves (MFMA-only time of a SIMD's two waves per point tile: hidden layer 4096, L0 1024, L5 5120, alpha+bott 4224, view 2304)")
+print("segment: median cycles over 32 WGs x 8 waves (MFMA-only time of a SIMD's two waves per point tile: hidden layer 4096, L0 1024, L5 5120, alpha+bott 4224, view 2304; this build has %d point tiles)" % NPT)
 for i in range(14):
     print(f"  {names[i]:>14s}: {np.median(d[:,:,i]):8.0f}  (p10 {np.percentile(d[:,:,i],10):8.0f} p90 {np.percentile(d[:,:,i],90):8.0f})")
 tot = ls[:,:,14]-ls[:,:,0]
-print("pass total median", np.median(tot), "ideal MFMA", 2*2344*16)
+print("pass total median", np.median(tot), "cycles; MFMA-only time of a SIMD's two waves:", 2*2344*8*NPT)
 print("wave skew at L1 start within WG 0 (cycles rel. to wave 0):", (ls[0,:,3]-ls[0,0,3]).tolist())

@@ -88,8 +88,11 @@ static void run(const char* name, const half8* in, float* out, unsigned long lon
     std::sort(clk.begin(), clk.end()), std::sort(cyc.begin(), cyc.end());
     const double mfma_per_simd = 2.0 * tiles * 8 * NPT;
     const double tflops = (double)cus * 8 * tiles * 8 * NPT * 16384.0 / (ms * 1e-3) / 1e12;
-    printf("%-44s NPT=%d: %7.1f TFLOP/s  clock %.3f GHz  %.2f cycles per MFMA per SIMD (busy %.3f)\n", name, NPT, tflops, clk[cus / 2],
-           cyc[cus / 2] / mfma_per_simd, 16.0 * mfma_per_simd / cyc[cus / 2]);
+    // cycles from the launch time and the in-kernel clock (a single wave's stamps would flatter the
+    // variants without a barrier, where the older wave of a SIMD finishes first)
+    const double cycles = clk[cus / 2] * 1e9 * ms * 1e-3;
+    printf("%-44s NPT=%d: %7.1f TFLOP/s  clock %.3f GHz  %.2f cycles per MFMA per SIMD (pipe busy %.3f)\n", name, NPT, tflops, clk[cus / 2],
+           cycles / mfma_per_simd, 16.0 * mfma_per_simd / cycles);
 }
 
 int main() {
