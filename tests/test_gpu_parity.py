@@ -410,15 +410,16 @@ def test_mlp_forward_rays_equals_pts(gpu):
     assert torch.equal(raw_r, raw_p)
 
 
-@pytest.mark.parametrize("S", [5, 31, 33, 300])
+@pytest.mark.parametrize("S", [5, 31, 33, 47, 48, 49, 300])
 def test_mlp_many_tiles_per_workgroup(gpu, S):
-    """More 256-point tiles than workgroups, rays shorter and longer than a wave's 32 points and
-    a ragged last tile: every point's output equals that of the same point evaluated alone with
-    its ray's direction (one point per ray), and that of a small call on a slice of the rays."""
+    """More workgroup tiles (384 points: 8 waves x 48) than workgroups, rays shorter and longer than
+    a wave's 48 points (and than the 32 of the training forward) and a ragged last tile: every
+    point's output equals that of the same point evaluated alone with its ray's direction (one
+    point per ray), and that of a small call on a slice of the rays."""
     from nerf_amd import ops
     rng = np.random.default_rng(S)
     model = _model_from(trained_like_weights(rng), gpu)
-    n = (256 * 256 * 2 + 1234) // S + 1          # > 2 tiles per workgroup on a 256-CU chip
+    n = (384 * 256 * 2 + 1234) // S + 1          # > 2 tiles per workgroup on a 256-CU chip
     rb = synthetic_rays(n, seed=S)
     rays = _t(rb, gpu)
     z = ops.sample_z(rays, S)
