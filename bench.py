@@ -94,6 +94,19 @@ def pmc_traffic_per_launch(kernel="mlp_fwd_wide_kernel<0, false,", summary=None)
     return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], f"{name}, same kernel sources"
 
 
+def backend_is_rccl():
+    import torch.distributed as dist
+    return dist.get_backend() == "nccl"
+
+
+def _max_over_ranks_on_host(t):
+    """Rehearsal backend (gloo): the reduction runs on a host copy."""
+    import torch.distributed as dist
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.MAX)
+    return h
+
+
 def synthetic_batch(n, seed, device):
     """Origins on a radius-4 sphere, directions toward uniform targets in [-1,1]^3, not normalised."""
     g = torch.Generator(device="cpu")
@@ -158,7 +171,7 @@ def train_leg(a, kw_train, models, dev, rank, world, fence):
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX) if backend_is_rccl() else t.copy_(_max_over_ranks_on_host(t))
         dt = float(t.item())
     assert np.isfinite(float(loss)), "training produced a non-finite loss"
     rays_per_s = world * a.n_rand * a.train_steps / dt
@@ -213,7 +226,7 @@ def strong_leg(a, kw_test, dev, rank, world, fence):
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt, dg], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX) if backend_is_rccl() else t.copy_(_max_over_ranks_on_host(t))
         dt, dg = float(t[0].item()), float(t[1].item())
     assert out['rgb_map'].shape == (n, 3) and bool(torch.isfinite(out['rgb_map']).all())
     return {"workload": "one 800x800 view, 640000 rays, 64+128 samples, chunk 32768, ray batch sharded over the ranks",
@@ -237,33 +250,40 @@ def main():
                     help="headline: weak = every rank renders its own --rays batch; strong = one 800x800 view sharded over the ranks")
     a = ap.parse_args()
 
+    if os.environ.get("NERF_BENCH_WATCHDOG"):  # rehearsals: a hung rank prints where it hangs and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["NERF_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a one-GPU box: NERF_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and
+    # NERF_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); the numbers of
+    # such a run mean nothing, it only walks the multi-rank code paths.
+    share_gpu = os.environ.get("NERF_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("NERF_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(0 if share_gpu else local_rank)
+    dev = torch.device("cuda", 0 if share_gpu else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from nerf_amd import ops
+    from nerf_amd import ops, parallel
     from nerf_amd.run_nerf import create_nerf, render
 
     torch.manual_seed(0)  # identical replicas of both networks on every rank
     kw_train, kw_test, _, _, models = create_nerf(make_args())
     o, d = synthetic_batch(a.rays, 1000 + rank, dev)
-    gathered = None
-    if world > 1:
-        gathered = [torch.empty((a.rays, 5), dtype=torch.float32, device=dev) for _ in range(world)]
-
     def step():
         rgb, disp, acc, _ = render(1, 1, 1., chunk=a.chunk, rays=(o, d), near=2., far=6., **kw_test)
-        if world > 1:
-            dist.all_gather(gathered, torch.cat([rgb, disp[:, None], acc[:, None]], -1))
+        if world > 1:  # the packed maps of every rank, in rank order (one all-gather, 20 B/ray)
+            parallel.gather_rows(torch.cat([rgb, disp[:, None], acc[:, None]], -1), world * a.rays)
         return rgb
 
     def fence():
@@ -285,7 +305,7 @@ def main():
     hbm_timing, ops.HBM_TIMING = ops.HBM_TIMING, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX) if backend_is_rccl() else t.copy_(_max_over_ranks_on_host(t))
         dt = float(t.item())
     assert bool(torch.isfinite(rgb).all()), "render produced non-finite colours"
 

@@ -32,6 +32,13 @@ def shard_rays(rays_flat, rank=None, world_size=None):
     return rays_flat[lo:hi]
 
 
+def _staged(t):
+    """The tensor a collective should be given: gloo moves device tensors through host copies of
+    its own and has been seen to stall doing so when two ranks share one GPU, so under gloo device
+    tensors are staged through the host explicitly (RCCL takes them as they are)."""
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+
+
 def gather_rows(local, n_total, group=None):
     """All-gathers per-ray rows [n_local, ...] from every rank into [n_total, ...] in ray order.
     Shards may differ in length by one, so each is padded to the longest before the collective."""
@@ -42,8 +49,10 @@ def gather_rows(local, n_total, group=None):
     pad = longest - local.shape[0]
     if pad:
         local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    device, local = local.device, _staged(local.contiguous())
     bufs = [torch.empty_like(local) for _ in range(w)]
-    dist.all_gather(bufs, local.contiguous(), group=group)
+    dist.all_gather(bufs, local, group=group)
+    bufs = [b.to(device) for b in bufs]
     parts = []
     for r, b in enumerate(bufs):
         lo, hi = shard_bounds(n_total, r, w)
@@ -75,7 +84,7 @@ def global_count(n_local, device=None):
     t = torch.tensor(float(n_local), dtype=torch.float64, device=device)
     _, w = world()
     if w > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        allreduce_sum_(t)
     return t
 
 
@@ -87,7 +96,18 @@ def allreduce_sum_(flat, async_op=False, group=None):
     _, w = world()
     if w == 1:
         return None
+    if flat.is_cuda and dist.get_backend() == "gloo":  # see _staged: through the host, synchronously
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return _Done() if async_op else None
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class _Done:
+    """Work handle of an exchange that has already finished."""
+    def wait(self):
+        return True
 
 
 def broadcast_parameters(models, src=0):
@@ -99,5 +119,8 @@ def broadcast_parameters(models, src=0):
         return
     for m in models:
         with torch.no_grad():
-            dist.broadcast(m.flat, src=src)
+            buf = _staged(m.flat)
+            dist.broadcast(buf, src=src)
+            if buf is not m.flat:
+                m.flat.copy_(buf)
         m.mark_dirty()

@@ -366,7 +366,6 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
     optimizer.apply_gradients(zip(gradients, grad_vars))
     loss = loss.detach()
     if world_size > 1:
-        import torch.distributed as dist
         loss = loss.clone()
-        dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+        parallel.allreduce_sum_(loss)
     return loss, psnr, psnr0
