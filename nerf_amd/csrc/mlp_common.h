@@ -19,7 +19,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DEV __device__ __forceinline__
 
 constexpr int kPrefetch = 4;  // A fragments held in registers ahead of the MFMA (<= 8)
-constexpr int kPointsPerWave = 32;
+constexpr int kPointsPerWave = 32;  // training kernels (saved tensors are laid out in 32-point wave tiles)
 constexpr int kWavesPerBlock = 8;
 constexpr int kPointsPerBlock = kPointsPerWave * kWavesPerBlock;
 

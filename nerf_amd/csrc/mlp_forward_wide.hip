@@ -247,7 +247,7 @@ DEV void wide_tile(PIPE& p, GetB&& getB, const Prev& prev) {
 }
 
 // One layer of NT output tiles of NK k-steps; its output becomes fragments 0..NT/2-1 of `out`
-// (both point tiles).  `before` finishes the tile that preceded the layer; the returned object
+// (every point tile).  `before` finishes the tile that preceded the layer; the returned object
 // finishes the layer's last tile.
 // TB, TE: only tiles TB .. TE-1 of the layer (a layer may be run in two parts whose B operands
 // come from different places).

@@ -7,7 +7,8 @@
 // l&15, the same k), D = 16(out) x 16(points) in fp32 (lane l: point l&15, rows 4(l>>4) + r in
 // its 4 registers).  Two finished output tiles 2s, 2s+1, converted to fp16, ARE the B fragment of
 // k-step s of the next layer: element j of lane group g is feature 32s + 16(j>>2) + 4g + (j&3).
-// A wave owns two point tiles (32 points) and uses every A fragment for both.
+// A wave owns two (training forward) or three (inference) point tiles and uses every A fragment
+// for all of them.
 //
 // Stream.  1 KiB fragments (64 lanes x 8 fp16, lane-linear) in consumption order, 16 per 16 KiB
 // chunk, then the fp32 biases, 16 per output tile in natural row order.
