@@ -30,6 +30,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT = 2 * 593408          # one network, use_viewdirs (run_nerf_helpers.py:95-112)
 MFMA_PEAK_TFLOPS = 2500.0            # dense fp16/bf16 MFMA, MI355X
+# what a bare v_mfma_f32_16x16x32_f16 loop on random register operands sustains on this pool's
+# MI355X under its power limit (tools/mfma_ceiling.hip, profiles/r02_mfma_ceiling.txt): context for
+# roofline.frac, which stays priced against the spec peak
+BARE_MFMA_LOOP_TFLOPS = 1880.0
 HBM_PEAK_GBS = 8000.0                # HBM3E, MI355X
 # bytes one optimisation step moves per query point by construction: saved fp16 activations and
 # ReLU masks written (167 KiB per 32 points), fp16 layer gradients written (154 KiB), masks read
@@ -349,6 +353,8 @@ def main():
                        "parallelism": f"ray-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "bare_mfma_loop": BARE_MFMA_LOOP_TFLOPS,
+                         "frac_of_bare_mfma_loop": round(achieved / BARE_MFMA_LOOP_TFLOPS, 4),
                          # bytes per launch from the committed counter passes (same launch shapes and
                          # kernel sources), not live; null with the reason when they do not match
                          "traffic": traffic, "traffic_source": traffic_note,
