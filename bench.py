@@ -191,7 +191,7 @@ def train_leg(a, kw_train, models, dev, rank, world, fence):
 
 
 def strong_leg(a, kw_test, dev, rank, world, fence):
-    """BASELINE config 4: ONE 800 x 800 novel view (640,000 rays, 64+128 samples, chunk 32768)
+    """The full-resolution novel-view configuration: ONE 800 x 800 view (640,000 rays, 64+128 samples, chunk 32768)
     with the ray batch sharded over the ranks (contiguous slices, nerf_amd.parallel.render_sharded)
     and one all-gather of the packed maps (rgb, disp, acc, depth: 24 B/ray) at the end.  Strong
     scaling: the work is fixed, value = 640,000 x steps / time."""
