@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_POINT = 2 * 593408          # one network, use_viewdirs (run_nerf_helpers.py:95-112)
 MFMA_PEAK_TFLOPS = 2500.0            # dense fp16/bf16 MFMA, MI355X
 # what a bare v_mfma_f32_16x16x32_f16 loop on random register operands sustains on this pool's
-# MI355X under its power limit (tools/mfma_ceiling.hip, profiles/r02_mfma_ceiling.txt): context for
+# MI355X under its power limit (tools/mfma_ceiling.hip; its output is kept under profiles/): context for
 # roofline.frac, which stays priced against the spec peak
 BARE_MFMA_LOOP_TFLOPS = 1880.0
 HBM_PEAK_GBS = 8000.0                # HBM3E, MI355X
