@@ -103,25 +103,46 @@ def init_nerf_weights(rng, D=8, W=256, input_ch=63, input_ch_views=27, output_ch
 
 
 def mlp_forward(weights, x, D=8, input_ch=63, input_ch_views=27, skips=(4,), use_viewdirs=True,
-                dtype=np.float64):
-    """run_nerf_helpers.py:89-114.  x is [m, input_ch + input_ch_views]; returns [m, 4] = (rgb, alpha)."""
+                dtype=np.float64, operand_dtype=None, alpha_operand_dtype='same'):
+    """run_nerf_helpers.py:89-114.  x is [m, input_ch + input_ch_views]; returns [m, 4] = (rgb, alpha).
+
+    `operand_dtype` (np.float16) emulates a matrix unit that takes its operands in that type and
+    accumulates wider: every kernel and every Dense layer's input is rounded to it, biases and sums
+    stay in `dtype`.  It is the arithmetic the fp16-MFMA kernel implements, so tests can separate
+    what rounding the operands costs (any such implementation pays it) from what the kernel adds.
+    `alpha_operand_dtype` overrides it for the two operands of the density head alone (the last
+    hidden activation as that head reads it, and its kernel), to price that head separately."""
+    def rounder(t):
+        if t is None:
+            return lambda a: a
+
+        def q(a):
+            with np.errstate(over='ignore'):
+                r = np.asarray(a, dtype=np.float64).astype(t)
+            big = np.finfo(t).max       # the kernel's conversions saturate instead of producing inf
+            return np.clip(r.astype(dtype), -big, big)
+        return q
+    q = rounder(operand_dtype)
+    qa = q if isinstance(alpha_operand_dtype, str) else rounder(alpha_operand_dtype)
     ws = [np.asarray(w, dtype=dtype) for w in weights]
     x = np.asarray(x, dtype=dtype)
-    pts, views = x[..., :input_ch], x[..., input_ch:input_ch + input_ch_views]
+    pts, views = q(x[..., :input_ch]), q(x[..., input_ch:input_ch + input_ch_views])
     h = pts
     for i in range(D):
-        h = np.maximum(h @ ws[2 * i] + ws[2 * i + 1], 0)
+        h_wide = np.maximum(h @ q(ws[2 * i]) + ws[2 * i + 1], 0)
+        h = q(h_wide)
         if i in skips:
             h = np.concatenate([pts, h], -1)          # :98-99, order [pts, h]
+            h_wide = h
     if use_viewdirs:
         o = 2 * D
-        alpha = h @ ws[o + 6] + ws[o + 7]              # :102 linear
-        bott = h @ ws[o + 0] + ws[o + 1]               # :103 linear (no ReLU)
+        alpha = qa(h_wide) @ qa(ws[o + 6]) + ws[o + 7]  # :102 linear
+        bott = q(h @ q(ws[o + 0]) + ws[o + 1])         # :103 linear (no ReLU)
         v = np.concatenate([bott, views], -1)          # :104-105
-        v = np.maximum(v @ ws[o + 2] + ws[o + 3], 0)   # :110
-        rgb = v @ ws[o + 4] + ws[o + 5]                # :111 linear
+        v = q(np.maximum(v @ q(ws[o + 2]) + ws[o + 3], 0))   # :110
+        rgb = v @ q(ws[o + 4]) + ws[o + 5]             # :111 linear
         return np.concatenate([rgb, alpha], -1)        # :112
-    return h @ ws[2 * D] + ws[2 * D + 1]               # :114
+    return h @ q(ws[2 * D]) + ws[2 * D + 1]            # :114
 
 
 def batchify(fn, chunk):
@@ -299,6 +320,7 @@ def render_rays(ray_batch, weights_coarse, N_samples, retraw=False, lindisp=Fals
     ret = {}
     if N_importance > 0:
         rgb0, disp0, acc0, depth0 = rgb_map, disp_map, acc_map, depth_map
+        raw0, weights0, z_vals0 = raw, weights, z_vals   # kept for tests that look at the coarse pass
         z_mid = dtype(.5) * (z_vals[..., 1:] + z_vals[..., :-1])
         z_samples = sample_pdf(z_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.),
                                u=pdf_u, dtype=dtype)
@@ -309,7 +331,9 @@ def render_rays(ray_batch, weights_coarse, N_samples, retraw=False, lindisp=Fals
         rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(
             raw, z_vals, rays_d, raw_noise_std, white_bkgd, noise1, scale_dists_by_ray_norm, dtype)
         ret.update(rgb0=rgb0, disp0=disp0, acc0=acc0, depth0=depth0,
-                   z_std=np.std(z_samples, -1), z_samples=z_samples)
+                   z_std=np.std(z_samples, -1), z_samples=z_samples, weights0=weights0, z_vals0=z_vals0)
+        if retraw:
+            ret['raw0'] = raw0
     ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map, depth_map=depth_map,
                weights=weights, z_vals=z_vals)
     if retraw:

@@ -109,8 +109,9 @@ def render_rays(rb, ws_c, ws_f, N_samples=64, N_importance=128, white_bkgd=False
         lower = torch.cat([z[..., :1], mids], -1)
         z = lower + (upper - lower) * perturb_u
     pts = o[:, None, :] + d[:, None, :] * z[..., :, None]
-    raw = run_network(pts, vd, ws_c, netchunk)
+    raw0 = raw = run_network(pts, vd, ws_c, netchunk)
     rgb0, disp0, acc0, w, depth0 = raw2outputs(raw, z, d, white_bkgd)
+    w0 = w
     z_mid = .5 * (z[..., 1:] + z[..., :-1])
     zs = sample_pdf(z_mid, w[..., 1:-1], N_importance, det=(pdf_u is None), u=pdf_u).detach()
     z, _ = torch.sort(torch.cat([z, zs], -1), -1)
@@ -118,7 +119,8 @@ def render_rays(rb, ws_c, ws_f, N_samples=64, N_importance=128, white_bkgd=False
     raw = run_network(pts, vd, ws_f, netchunk)
     rgb, disp, acc, w, depth = raw2outputs(raw, z, d, white_bkgd)
     return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth, rgb0=rgb0, disp0=disp0,
-                acc0=acc0, z_std=torch.std(zs, -1, unbiased=False), raw=raw, z_vals=z, weights=w)
+                acc0=acc0, z_std=torch.std(zs, -1, unbiased=False), raw=raw, z_vals=z, weights=w,
+                raw0=raw0, weights0=w0)
 
 
 def render_flat(rb, ws_c, ws_f, chunk=1024 * 32, **kw):

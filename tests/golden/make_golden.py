@@ -1,5 +1,7 @@
 """Generates tests/golden/render_core_v1.npz: seeded inputs and the fp64 oracle's outputs for every
-stage of the per-ray render core.
+stage of the per-ray render core, and tests/golden/render_core_v2.npz: the whole path once more on
+networks with the spectrum of a fitted field (tests/util.py:fitted_like_weights), with what a test
+needs to tell which rays crossed one of the reference's discontinuities.
 
 The reference itself cannot produce these (TensorFlow 1.15 is not installable here and its
 NERFCO submodule is absent), so the vectors come from oracle/nerf_oracle.py -- they freeze the
@@ -14,9 +16,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import nerf_oracle as orc  # noqa: E402
-from tests.util import pose_spherical, synthetic_rays, trained_like_weights  # noqa: E402
+from tests.util import fitted_like_weights, pose_spherical, synthetic_rays, trained_like_weights  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "render_core_v1.npz")
+OUT2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "render_core_v2.npz")
 
 
 def main():
@@ -90,6 +93,26 @@ def main():
     g['adam_traj'] = np.stack(traj)
     np.savez_compressed(OUT, **g)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+    # v2: the whole path, 64 + 128 and 64 + 64 samples, fitted-like networks
+    g2 = {'weights_seed': np.array([789, 1011])}
+    wc = fitted_like_weights(np.random.default_rng(789))
+    wf = fitted_like_weights(np.random.default_rng(1011))
+    g2['weights_checksum'] = np.array([float(sum(np.sum(w.astype(np.float64)) for w in wc)),
+                                       float(sum(np.sum(w.astype(np.float64)) for w in wf))])
+    rb = synthetic_rays(96, seed=78)
+    g2['rays'] = rb
+    for Si in (128, 64):
+        for white in (0, 1):
+            r = orc.render_rays(rb, wc, 64, retraw=True, N_importance=Si, weights_fine=wf, white_bkgd=bool(white),
+                                dtype=np.float64)
+            tag = f'e2e_{Si}_white{white}_'
+            for k in ['rgb_map', 'disp_map', 'acc_map', 'depth_map', 'rgb0', 'acc0', 'z_std', 'weights0']:
+                g2[tag + k] = r[k]
+            g2[tag + 'raw0_last'] = r['raw0'][:, -1:, :]   # [N,1,4]: the samples whose sigma's sign is a step
+            g2[tag + 'raw_last'] = r['raw'][:, -1:, :]
+    np.savez_compressed(OUT2, **g2)
+    print("wrote", OUT2, os.path.getsize(OUT2), "bytes")
 
 
 if __name__ == "__main__":

