@@ -36,9 +36,9 @@ MFMA_PEAK_TFLOPS = 2500.0            # dense fp16/bf16 MFMA, MI355X
 BARE_MFMA_LOOP_TFLOPS = 1880.0
 HBM_PEAK_GBS = 8000.0                # HBM3E, MI355X
 # bytes one optimisation step moves per query point by construction: saved fp16 activations and
-# ReLU masks written (167 KiB per 32 points), fp16 layer gradients written (154 KiB), masks read
-# by the chain (9 KiB), every saved block read once for the weight gradients (318 KiB)
-TRAIN_BYTES_PER_POINT = (167 + 154 + 9 + 318) * 1024 / 32
+# ReLU masks written (151 KiB per 32 points), fp16 layer gradients written (138 KiB), masks read
+# by the chain (9 KiB), every saved block read once for the weight gradients (284 KiB)
+TRAIN_BYTES_PER_POINT = (151 + 138 + 9 + 284) * 1024 / 32
 N_RAYS = 1024 * 1024
 N_SAMPLES, N_IMPORTANCE = 64, 128
 

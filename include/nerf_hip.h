@@ -197,8 +197,10 @@ int nerf_composite_bwd(const float* raw, const float* z, const float* rays_d, in
 /* Bytes of activation scratch nerf_mlp_forward_train needs for n_points query points. */
 size_t nerf_mlp_act_bytes(int64_t n_points);
 
-/* nerf_mlp_forward_rays that also saves every layer's fp16 activations into `act`
- * (nerf_mlp_act_bytes(n_rays*S) bytes) for nerf_mlp_backward. */
+/* nerf_mlp_forward_rays that also saves the fp16 activations the backward pass needs into `act`
+ * (nerf_mlp_act_bytes(n_rays*S) bytes) for nerf_mlp_backward: both encodings, the outputs of the
+ * eight point layers and of the view layer, and their ReLU masks.  The bottleneck
+ * (run_nerf_helpers.py:103) is linear and is not saved (nerf_mlp_backward composes its gradient). */
 int nerf_mlp_forward_train(const void* packed, const float* rays, int width, const float* z,
                            int64_t n_rays, int S, float* raw, void* act, nerf_stream_t stream);
 
@@ -206,6 +208,13 @@ int nerf_mlp_forward_train(const void* packed, const float* rays, int width, con
  * from the same 24 parameter arrays as nerf_mlp_pack. */
 size_t nerf_mlp_packed_bwd_bytes(void);
 int nerf_mlp_pack_bwd(const float* const* params, void* packed_bwd, nerf_stream_t stream);
+
+/* Where the saved tensors lie, for tools and tests that decode them: both buffers are
+ * [32-point wave tile][block][1 KiB].  out[0..9] = blocks per tile of `act`, first block of the
+ * point encoding, of h0 (16 blocks per layer output), of the view layer's output, of the view
+ * encoding, of the ReLU mask blocks; blocks per tile of `gbuf`, first block of d(view layer
+ * pre-activation), of d(pre-activation of layer 0) (16 per layer), of d(alpha).  n: room in out. */
+int nerf_mlp_train_layout(int32_t* out, int n);
 
 /* Scratch sizes of nerf_mlp_backward: fp16 layer gradients for n_points, and the fp32
  * partial-sum buffer (fixed size for the current device: a status block, the summed
@@ -227,7 +236,9 @@ size_t nerf_mlp_partial_bytes(void);
  * whether a layer gradient saturated the fp16 range (or was not finite) or everything sank below
  * the smallest normal fp16; when either happened the gradients are written as NaN, never as
  * plausible numbers (read the bits with nerf_mlp_backward_status).
- * Weight gradients are summed in a fixed order: the same inputs give the same bits.
+ * Weight gradients are summed in a fixed order: the same inputs give the same bits.  The gradients
+ * of the bottleneck layer and of the view layer's bottleneck rows are formed as products of
+ * sum_points h7 (x) d v_pre with the two layers' fp32 weights (kept behind the stream in packed_bwd).
  * accumulate != 0 adds into grads instead of overwriting.  No gradient flows to rays or depths. */
 int nerf_mlp_backward(const void* packed_bwd, const void* act, const float* d_raw, int64_t n_points,
                       float gscale, void* gbuf, void* partial, float* const* grads, int accumulate,

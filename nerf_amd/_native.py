@@ -40,6 +40,7 @@ SIGNATURES = {
     "nerf_composite_bwd": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "nerf_mlp_act_bytes": (_c.c_size_t, [_L]),
     "nerf_mlp_forward_train": (_I, [_P, _P, _I, _P, _L, _I, _P, _P, _P]),
+    "nerf_mlp_train_layout": (_I, [_P, _I]),
     "nerf_mlp_packed_bwd_bytes": (_c.c_size_t, []),
     "nerf_mlp_pack_bwd": (_I, [_P, _P, _P]),
     "nerf_mlp_grad_bytes": (_c.c_size_t, [_L]),

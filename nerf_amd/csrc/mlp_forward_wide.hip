@@ -9,8 +9,8 @@
 // run, the weight stream already refills the ring for the next tile and the next tile's rays
 // and depths are fetched, so a CU never waits for a workgroup launch, a cold ring or its inputs.
 // A layer is computed one 16-row output tile at a time: one A fragment per k-step feeds NPT
-// v_mfma_f32_16x16x32_f16 (one per point tile), 2 x NPT x 4 fp32 accumulator registers seeded
-// with the biases.  A finished tile is converted (fp16 rounding, then a packed ReLU) in 2 NPT
+// v_mfma_f32_16x16x32_f16 (one per point tile), 2 x NPT x 4 fp32 accumulator registers; the
+// first k-step of a tile adds to the tile's bias registers (read from LDS a few k-steps earlier).  A finished tile is converted (fp16 rounding, then a packed ReLU) in 2 NPT
 // slices placed between the MFMAs of the FOLLOWING tile, so the matrix pipe never waits behind a
 // block of conversion instructions; two consecutive tiles make one B fragment of the next layer.
 // Two fragment sets ping-pong between layers.
@@ -93,6 +93,7 @@ struct WidePipe {
     STREAM& st;
     const char* bias;   // bias table in LDS, already offset by this lane group's 16 bytes
     f32x4 acc[2][NPT];  // [tile parity][point tile]
+    f32x4 seed;         // the biases of the NEXT output tile: srcC of its first k-step (no register copies)
 };
 
 // Where a training forward saves its fragments: [wave tile][block][lane] (inference: unused).
@@ -221,8 +222,8 @@ static_assert(w_last_slice_step(2, 3) < 2 && w_last_slice_step(4, 3) < 3 && w_la
 
 // Output tile T (= its bias tile): NK k-steps of fragments F0..; getB(pt, k) is the B fragment of
 // point tile pt.  Every k-step is one scheduling region: two MFMAs, the LDS read of the A
-// fragment kPrefetch steps ahead, a slice of the previous tile and, late in the tile, the bias
-// seed of the next one.
+// fragment kPrefetch steps ahead, a slice of the previous tile and, late in the tile, the LDS read
+// of the next tile's biases.
 template <int F0, int NK, int T, class PIPE, class GetB, class Prev>
 DEV void wide_tile(PIPE& p, GetB&& getB, const Prev& prev) {
     static_for<0, NK>([&](auto kc) {
@@ -231,17 +232,16 @@ DEV void wide_tile(PIPE& p, GetB&& getB, const Prev& prev) {
         const half8 a = p.st.template take<F0 + k>();
         static_for<0, NPT>([&](auto ptc) {
             constexpr int pt = decltype(ptc)::value;
-            p.acc[T & 1][pt] = mfma_wide(a, getB(ptc, kc), p.acc[T & 1][pt]);
+            // the first k-step takes the bias tile as its addend: the accumulators are never seeded by copies
+            if constexpr (k == 0) p.acc[T & 1][pt] = mfma_wide(a, getB(ptc, kc), p.seed);
+            else p.acc[T & 1][pt] = mfma_wide(a, getB(ptc, kc), p.acc[T & 1][pt]);
         });
         if constexpr (Prev::kActive && k >= w_first_slice_step(NK)) {
             constexpr int sp = w_slices_per_step(NK, NPT), s0 = (k - w_first_slice_step(NK)) * sp;
             static_for<(s0 < NS ? s0 : NS), (s0 + sp < NS ? s0 + sp : NS)>(
                 [&](auto sc) { prev.template slice<decltype(sc)::value>(p.acc[(T & 1) ^ 1]); });
         }
-        if constexpr (k == w_bias_step(NK, NPT) && T + 1 < lw::T_END) {
-            const f32x4 b = *(const f32x4*)(p.bias + (T + 1) * 64);
-            static_for<0, NPT>([&](auto ptc) { p.acc[(T & 1) ^ 1][decltype(ptc)::value] = b; });
-        }
+        if constexpr (k == w_bias_step(NK, NPT) && T + 1 < lw::T_END) p.seed = *(const f32x4*)(p.bias + (T + 1) * 64);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
     // read is this register + an immediate (the table lies beyond a ds_read's 16-bit offset)
     unsigned bias_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + kWRingBytes + g * 16);
     asm volatile("" : "+v"(bias_addr));
-    WidePipe<WideStream, NPT> pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}};
+    WidePipe<WideStream, NPT> pp{st, (const char*)(__attribute__((address_space(3))) const char*)(uintptr_t)bias_addr, {}, {}};
 
     // ---- this lane's two query points (one per point tile) of the workgroup's first tile ----
     RayCursor where(blockIdx.x, wave, a.S, kPB, kPW);
@@ -520,11 +520,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
         LSTAMP(1);
         st.start();
         LSTAMP(2);
-        {
-            const f32x4 b = *(const f32x4*)(pp.bias);
-#pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) pp.acc[0][pt] = b;
-        }
+        pp.seed = *(const f32x4*)(pp.bias);
         auto c0 = wide_layer<lw::F_L0, 16, 2, lw::T_L0, true, STORE, A_H0, A_MASK + 0>(pp, sink, mk, fa, from_pe, WNoPrev{});                     // layer 0
         LSTAMP(3);
         auto c1 = wide_layer<lw::F_L1 + 0 * 128, 16, 8, lw::T_L1 + 0, true, STORE, A_H0 + 16, A_MASK + 1>(pp, sink, mk, fb, from_a, c0);        // layers 1..4
@@ -575,7 +571,8 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fwd_wide_kernel(FwdWideArgs a)
             lvpe[0].issue(vm, act_tile + A_VPE * kFragBytes, lane * 16);
             lvpe[1].issue(vm, act_tile + (A_VPE + 1) * kFragBytes, lane * 16);
         }
-        auto c8 = wide_layer<lw::F_BOTT, 16, 8, lw::T_BOTT, false, STORE, A_BOTT, -1>(pp, sink, mk, fa, from_b, WKeepRow0{sigma});
+        // (linear, and not saved for the backward pass: see the note at kActBlocks)
+        auto c8 = wide_layer<lw::F_BOTT, 16, 8, lw::T_BOTT, false, false, 0, -1>(pp, sink, mk, fa, from_b, WKeepRow0{sigma});
         LSTAMP(11);
         half8 vpe9[NPT];
         if constexpr (STORE) vpe9[0] = lvpe[0].get(vm), vpe9[1] = lvpe[1].get(vm);

@@ -32,23 +32,28 @@ constexpr int kChunkBytes = kFragBytes * kFragsPerChunk;
 // 8 features lw::acc_feature(s, g, 0..7) (encodings: lw::pe_feature / lw::view_feature).
 constexpr int A_PE = 0;      //  4 blocks: point encoding (64 slots)
 constexpr int A_H0 = 4;      // 16 blocks per layer output h0..h7 (after ReLU): A_H0 + 16*l
-constexpr int A_BOTT = 132;  // 16 blocks: bottleneck (linear)
-constexpr int A_V = 148;     //  8 blocks: view layer output (after ReLU)
-constexpr int A_VPE = 156;   //  2 blocks: view-direction encoding (32 slots)
-constexpr int A_MASK = 158;  //  1 block per layer output h0..h7 and one for v (A_MASK + 8): ReLU masks, one
+constexpr int A_V = 132;     //  8 blocks: view layer output (after ReLU)
+constexpr int A_VPE = 140;   //  2 blocks: view-direction encoding (32 slots)
+constexpr int A_MASK = 142;  //  1 block per layer output h0..h7 and one for v (A_MASK + 8): ReLU masks, one
                              //  bit per unit: lane = point + 16 g holds dwords [point tile][2]; with
                              //  i = 2 t + (r >> 1), bit (i & 15) + 16 (r & 1) of dword i >> 4 = unit
                              //  16 t + 4 g + r is > 0
-constexpr int kActBlocks = 167;
+constexpr int kActBlocks = 151;
+// The bottleneck (run_nerf_helpers.py:103) is linear, so neither its output nor its gradient is
+// saved: with P = sum over points of h7 (x) d v_pre and s = sum of d v_pre, the gradients of the two
+// layers around it are products of P with the layers' own weights (see mlp_head_compose_kernel),
+//     dW_bott = P . W_view[0:256]^T          db_bott = W_view[0:256] . s
+//     dW_view[0:256] = W_bott^T . P + b_bott (x) s
+// which takes 32 of 318 blocks out of what the weight-gradient kernel reads per 32 points, 16 out
+// of what the forward pass writes and 16 out of what the gradient chain writes.
 
 // Gradients come from the 32x32x16 chain: a block is k-step k (16 features) of the 32 points,
 // lane = point + 32 h holds the 8 features acc_feature(k, h, 0..7).
 constexpr int G_DV = 0;      //  8 blocks: d(view layer pre-activation)
-constexpr int G_DBOTT = 8;   // 16 blocks: d(bottleneck)
-constexpr int G_DPRE0 = 24;  // 16 blocks per layer: d(pre-activation of layer l): G_DPRE0 + 16*l
-constexpr int G_DA = 152;    //  1 block: d(alpha) in feature slot 0
-constexpr int G_DC = 153;    //  1 block: d(rgb) in feature slots 0..2
-constexpr int kGradBlocks = 154;
+constexpr int G_DPRE0 = 8;   // 16 blocks per layer: d(pre-activation of layer l): G_DPRE0 + 16*l
+constexpr int G_DA = 136;    //  1 block: d(alpha) in feature slot 0
+constexpr int G_DC = 137;    //  1 block: d(rgb) in feature slots 0..2
+constexpr int kGradBlocks = 138;
 
 // ---- backward weight stream: d h_in = W . d y, A = W[in][out] with the out index permuted as
 // the incoming gradient fragments are ----
@@ -59,7 +64,12 @@ constexpr int B_H6 = 204;    // 16 x 8   x7: d pre_{l+1} -> d h_l for l = 6..0 (
 constexpr int B_END_USED = 1100;
 constexpr int B_END = 1104;  // padded to a chunk boundary
 constexpr int kBwdChunks = B_END / kFragsPerChunk;  // 69
-constexpr size_t kPackedBwdBytes = (size_t)kBwdChunks * kChunkBytes;
+// behind the stream, in fp32 and natural order, the three arrays mlp_head_compose_kernel multiplies by:
+// the bottleneck's kernel [256][256] and bias [256], and rows 0..255 of the view layer's kernel [256][128]
+constexpr size_t kBwdBottW = (size_t)kBwdChunks * kChunkBytes;
+constexpr size_t kBwdBottB = kBwdBottW + 256 * 256 * sizeof(float);
+constexpr size_t kBwdViewW = kBwdBottB + 256 * sizeof(float);
+constexpr size_t kPackedBwdBytes = kBwdViewW + 256 * 128 * sizeof(float);
 static_assert(B_H6 + 7 * 128 == B_END_USED && B_END % kFragsPerChunk == 0, "backward stream");
 
 // Feature of the previous layer's output held by element j of lane half h in k-step k

@@ -17,10 +17,14 @@
 //     kernel then adds the partial tiles of a job in workgroup order (no atomics: the same inputs
 //     give the same bits).  Bias
 //     gradients are the sums of the gradient operand over the points.  Layers whose input is
-//     a concatenation (layer 5, view layer) and heads that share an input (bottleneck, alpha) are
-//     one job each, so every saved block is read once.  HBM-bound: ~9.9 KB/point read for
-//     1.19 MFLOP/point.
-//  3. mlp_grad_unpack_kernel -- accumulator-ordered sums -> the 24 arrays, times 1/gscale.
+//     a concatenation (layer 5) and products that share an operand (the view layer's gradient
+//     against h7 and against the view encoding, the alpha head's gradient against h7) are one job
+//     each, so every saved block is read once.  HBM-bound: ~8.9 KB/point read.
+//  3. mlp_grad_unpack_kernel -- accumulator-ordered sums -> the parameter arrays, times 1/gscale.
+//  4. mlp_head_compose_kernel -- the bottleneck is linear, so its gradient and that of the view
+//     layer's bottleneck rows are small matrix products of P = sum_points h7 (x) d v_pre with the
+//     two layers' own fp32 weights (mlp_layout.h, at kActBlocks); neither the bottleneck nor its
+//     gradient is ever stored.
 //
 // The gradient scale.  The chain carries gradients in fp16, so d raw is multiplied by a power of
 // two on entry and the result divided by it on exit.  By default the factor is formed on the
@@ -99,9 +103,20 @@ struct ParamPtrsB {
     const float* p[24];
 };
 
+// fp32 arrays kept behind the stream for mlp_head_compose_kernel, in blocks of 256 floats
+constexpr int kBwdCopyBlocks = (256 * 256 + 256 + 256 * 128) / 256;
+
 __global__ __launch_bounds__(64) void mlp_pack_bwd_kernel(ParamPtrsB pp, char* __restrict__ packed) {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int F = blockIdx.x;
+    if (F >= B_END) {  // bottleneck kernel, bottleneck bias, the view layer's first 256 rows: contiguous at kBwdBottW
+        const int q = (F - B_END) * 64 + lane;  // float4 index
+        const float4* src = q < 16384 ? (const float4*)pp.p[16] + q
+                          : q < 16384 + 64 ? (const float4*)pp.p[17] + (q - 16384)
+                                           : (const float4*)pp.p[18] + (q - 16384 - 64);
+        ((float4*)(packed + kBwdBottW))[q] = *src;
+        return;
+    }
     const float* Wm = nullptr;  // kernel [in, out]
     int out_dim = 0, in = -1, in_rows = 0;
     int outs[8];
@@ -204,7 +219,8 @@ struct ChainPipe {
 
 // What happens to a finished gradient tile: eight slices (two registers -> one packed dword,
 // saturated to the fp16 range by the conversion, multiplied by the unit's ReLU mask bits) run between the MFMAs of the
-// following tile; finished fragments are stored as blocks GBLK + 2*TL, +1 for the dW kernel.
+// following tile; finished fragments are stored as blocks GBLK + 2*TL, +1 for the dW kernel
+// (GBLK < 0: not stored -- the bottleneck's gradient only feeds the next layer of the chain).
 struct CNoPrev {
     static constexpr bool kActive = false;
     template <int S> DEV void slice(const f32x16&) const {}
@@ -230,7 +246,7 @@ struct CToFrags {
         }
         half8& f = dst[2 * TL + (S >> 2)];
         f[2 * (S & 3)] = p[0], f[2 * (S & 3) + 1] = p[1];
-        if constexpr ((S & 3) == 3) sink.template put<GBLK + 2 * TL + (S >> 2)>(f);
+        if constexpr ((S & 3) == 3 && GBLK >= 0) sink.template put<GBLK + 2 * TL + (S >> 2)>(f);
     }
 };
 
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
     // each layer's mask bits are requested one layer before they are needed
     auto c0 = chain_layer<B_V, 4, 1, true, G_DV>(pp, sink, mv.get(vm), fa, [&](auto) { return dC; }, CNoPrev{});   // d v_pre
     m6.issue(vm, masks + 6 * kFragBytes, lane);
-    auto c1 = chain_layer<B_BOTT, 8, 8, false, G_DBOTT>(pp, sink, none, fb, from_a, c0);                           // d bott
+    auto c1 = chain_layer<B_BOTT, 8, 8, false, -1>(pp, sink, none, fb, from_a, c0);                                // d bott (not stored)
     auto c2 = chain_layer<B_H7, 8, 17, true, G_DPRE0 + 16 * 7>(pp, sink, m7.get(vm), fa, [&](auto kc) {            // d pre7
         constexpr int k = decltype(kc)::value;
         if constexpr (k < 16) return fb[k]; else return dA;
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
 constexpr int kDwStageBytes = 40 * kFragBytes;  // one ring stage: a group of wave tiles of one job
 constexpr int kDwStages = 4;
 constexpr int kDwAhead = 3;      // input operands in flight ahead of their MFMA
-constexpr int kNumJobs = 11;     // what a workgroup can be given (see make_jobs)
+constexpr int kNumJobs = 10;     // what a workgroup can be given (see make_jobs)
 constexpr int kNumProducts = 12; // (layer input, layer gradient) products the unpack kernel reads
 
 // One job = one gradient segment y (NY tiles of 32 outputs) against one or two input segments x
@@ -474,17 +490,19 @@ DEV void dw_stage_in(const DwStageSrc s, int64_t group, char* dst, int wave) {
 // issued twice and workgroups are handed out in proportion to the loads of a job.
 //
 // Accumulator tiles of the partial-sum buffer, from jb.tile0: output tile w x input i at
-// w * NI + i (i = NX: the bias, in column 0); the single-row gradient x input i at n_out * NI + i.
+// w * NI + i (i = NX: the bias, in column 0); the single-row gradient x tile i of the FIRST input
+// segment at n_out * NI + i (i = NX0: its bias).
 //
 // ROW: the job has one output tile (rgb).  Giving it to one wave would leave that wave alone with
 // every MFMA of the job, so the waves split the INPUT tiles instead: wave w accumulates the
 // product with input tile w (wave 0 also takes the bias).  The single-row gradient of an NY1
-// job is handled the same way on top of the wave's own output tile.
+// job is handled the same way (wave w: tile w of the first segment) on top of the wave's own
+// output tile.
 template <int NX0, int NX1, int NY, int NY1, int BIAS, int G, bool ROW = false>
 DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave) {
     constexpr int NX = NX0 + NX1, NI = NX + BIAS;
     static_assert(!ROW || (NY == 1 && NY1 == 0 && NX <= kWavesPerBlock), "row jobs: one gradient tile, one input tile per wave");
-    static_assert(NY1 == 0 || (NY1 == 1 && !ROW && NX <= kWavesPerBlock), "a second gradient is a single row split over the waves");
+    static_assert(NY1 == 0 || (NY1 == 1 && !ROW && NX0 <= kWavesPerBlock), "a second gradient is a single row against the first input segment, split over the waves");
     constexpr int kTileUnits = 2 * (NX + NY + NY1);            // 1 KiB loads per wave tile
     constexpr int kUnits = kTileUnits * G;                     // per stage
     constexpr int kMine = (kUnits + kWavesPerBlock - 1) / kWavesPerBlock;  // loads per stage of waves < kFullWaves,
@@ -510,7 +528,7 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
     f32x16 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = zero16;
-    f32x16 accr = zero16;  // NY1: single-row gradient x input tile `wave`
+    f32x16 accr = zero16;  // NY1: single-row gradient x tile `wave` of the first input segment
     // Bias gradients = sums of the gradient operand over the points.  A lane of that operand holds
     // 8 points of output row (lane & 31), so one fp32 register per lane takes the sum (v_dot2 with
     // ones) and the two lane halves meet in the atomic add at the end.
@@ -579,25 +597,17 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
                         }
                     }
                 } else {
-                    if (wave < jb.n_out) {
 #pragma unroll
-                        for (int gt = 0; gt < G; ++gt) {
-                            if (it * G + gt < ntile) {
-                                const char* stage = lds + buf * kDwStageBytes + gt * kTileBytes;
+                    for (int gt = 0; gt < G; ++gt) {
+                        if (it * G + gt < ntile) {
+                            const char* stage = lds + buf * kDwStageBytes + gt * kTileBytes;
+                            if (wave < jb.n_out) {
                                 // 2 NX products, input operands read kDwAhead products ahead of
                                 // their MFMA (the compiler, left alone, reads each operand right
                                 // before its use and every MFMA then waits a full LDS round trip)
                                 half8 ya[2], q[kDwAhead];
                                 ya[0] = tr_operand(stage + (NX + wave) * kTileImgBytes, 0, lane, y_one);
                                 ya[1] = tr_operand(stage + (NX + wave) * kTileImgBytes, 1, lane, y_one);
-                                half8 yr[2], xr[2];  // NY1: the single-row gradient and this wave's input tile
-                                if constexpr (NY1) {
-#pragma unroll
-                                    for (int kp = 0; kp < 2; ++kp) {
-                                        yr[kp] = tr_operand(stage + (NX + NY) * kTileImgBytes, kp, lane, true);
-                                        xr[kp] = tr_operand(stage + wave * kTileImgBytes, kp, lane, false);
-                                    }
-                                }
                                 static_for<0, kDwAhead>([&](auto mc) {
                                     constexpr int m = decltype(mc)::value;
                                     q[m] = tr_operand(stage + (m % NX) * kTileImgBytes, m / NX, lane, false);
@@ -615,7 +625,15 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
                                 });
                                 if constexpr (BIAS) bsum = point_sum(ya[1], point_sum(ya[0], bsum));
                                 track(ya[0]), track(ya[1]);
-                                if constexpr (NY1) {
+                            }
+                            if constexpr (NY1) {
+                                if (wave < NX0) {  // the single-row gradient against this wave's tile of the first segment
+                                    half8 yr[2], xr[2];
+#pragma unroll
+                                    for (int kp = 0; kp < 2; ++kp) {
+                                        yr[kp] = tr_operand(stage + (NX + NY) * kTileImgBytes, kp, lane, true);
+                                        xr[kp] = tr_operand(stage + wave * kTileImgBytes, kp, lane, false);
+                                    }
                                     accr = mfma(yr[1], xr[1], mfma(yr[0], xr[0], accr));
                                     if constexpr (BIAS) bsum_r = point_sum(yr[1], point_sum(yr[0], bsum_r));
                                     if (wave == 0) track(yr[0]), track(yr[1]);
@@ -660,9 +678,9 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
             for (int i = 0; i < NX; ++i) flush(wave * NI + i, acc[i]);
             if constexpr (BIAS) flush_bias(wave * NI + NX, bsum);
         }
-        if constexpr (NY1) {
-            if (wave < NX) flush(jb.n_out * NI + wave, accr);
-            if (BIAS && wave == 0) flush_bias(jb.n_out * NI + NX, bsum_r);
+        if constexpr (NY1) {  // its row of tiles: the NX0 input tiles, then the bias
+            if (wave < NX0) flush(jb.n_out * NI + wave, accr);
+            if (BIAS && wave == 0) flush_bias(jb.n_out * NI + NX0, bsum_r);
         }
     }
     // the workgroup's largest gradient pattern -> one atomic per workgroup (LDS is free: every
@@ -688,7 +706,7 @@ DEV void dw_body(const DwArgs& a, const DwJob& jb, char* lds, int lane, int wave
     }
 }
 
-enum DwKind { DW_HIDDEN, DW_LAYER0, DW_LAYER5, DW_BOTT_ALPHA, DW_VIEW, DW_RGB };
+enum DwKind { DW_HIDDEN, DW_LAYER0, DW_LAYER5, DW_HEADS, DW_RGB };
 
 __global__ __launch_bounds__(512) void mlp_dw_kernel(DwArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[kDwStages * kDwStageBytes];
@@ -714,8 +732,7 @@ __global__ __launch_bounds__(512) void mlp_dw_kernel(DwArgs a) {
         case DW_HIDDEN: dw_body<8, 0, 8, 0, 1, 1>(a, jb, lds, lane, wave); break;        // layers 1-4, 6, 7
         case DW_LAYER0: dw_body<2, 0, 8, 0, 1, 2>(a, jb, lds, lane, wave); break;        // point encoding -> 256
         case DW_LAYER5: dw_body<8, 2, 8, 0, 1, 1>(a, jb, lds, lane, wave); break;        // [h4 ; point encoding] -> 256
-        case DW_BOTT_ALPHA: dw_body<8, 0, 8, 1, 1, 1>(a, jb, lds, lane, wave); break;    // h7 -> bottleneck and alpha
-        case DW_VIEW: dw_body<8, 1, 4, 0, 1, 1>(a, jb, lds, lane, wave); break;          // [bottleneck ; view encoding] -> 128
+        case DW_HEADS: dw_body<8, 1, 4, 1, 1, 1>(a, jb, lds, lane, wave); break;         // [h7 ; view encoding] x d v_pre, h7 x d alpha
         default: dw_body<4, 0, 1, 0, 1, 3, true>(a, jb, lds, lane, wave); break;         // rgb
     }
 }
@@ -761,10 +778,12 @@ struct UnpackArgs {
     float gscale;      // > 0: the caller's factor; otherwise the one formed from status[ST_ABSMAX]
     unsigned* status;
     int accumulate;
-    int tile0[kNumProducts];  // per product (0..7 point layers, 8 bottleneck, 9 view, 10 rgb, 11 alpha):
+    int tile0[kNumProducts];  // per product (0..7 point layers, 8 bottleneck: none, 9 view, 10 rgb, 11 alpha):
     int n_in[kNumProducts];   // first accumulator tile, and input tiles per output tile (bias tile last)
     int first[25];  // first flat index of each parameter array (get_weights order); [24] = total
+    float* pext;    // [257][128]: P = sum_points h7 (x) d v_pre in natural order, then s = sum_points d v_pre
 };
+constexpr int kPextRows = 257, kPextCols = 128;
 
 // (inputs, outputs) of the 12 layers in get_weights() order
 __device__ const int kLayerDims[12][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
@@ -818,7 +837,21 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
         a.status[ST_ABSMAX_OUT] = absmax;
         a.status[ST_YMAX_OUT] = ymax;
     }
-    if (gi >= a.first[24]) return;
+    const float inv = 1.0f / gs;
+    if (gi >= a.first[24]) {
+        // the operand of mlp_head_compose_kernel: the view layer's product with h7 (and its bias sums)
+        const int q = gi - a.first[24];
+        if (q >= kPextRows * kPextCols) return;
+        const int i = q / kPextCols, j = q % kPextCols;
+        int ot, orow, it, irow;
+        acc_slot(j, ot, orow);
+        if (i < 256) in_slot(i, it, irow); else it = a.n_in[9] - 1, irow = 0;
+        const int reg = (orow & 3) + 4 * (orow >> 3), lane = 32 * ((orow >> 2) & 1) + irow;
+        float v = a.gperm[((size_t)(a.tile0[9] + ot * a.n_in[9] + it) * 16 + reg) * 64 + lane] * inv;
+        if (flags) v = __builtin_nanf("");
+        a.pext[q] = v;
+        return;
+    }
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < 24; ++i)
@@ -828,6 +861,8 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
     const bool is_bias = pi & 1;
     const int layer = pi >> 1;  // 0..7 point layers, 8 bottleneck, 9 view, 10 rgb, 11 alpha
     const int in = is_bias ? -1 : e / out_dim, out = is_bias ? e : e % out_dim;
+    // the bottleneck's arrays and the view layer's bottleneck rows are written by mlp_head_compose_kernel
+    if (layer == 8 || (layer == 9 && !is_bias && in < 256)) return;
     int ot, orow, it, irow;
     if (layer == 10 || layer == 11) ot = 0, orow = out;           // d rgb slots 0..2 / d alpha slot 0
     else acc_slot(out, ot, orow);
@@ -835,16 +870,78 @@ __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
     else if (layer == 0) pe_slot(in, it, irow);
     else if (layer == 5) {       // input tiles: h4 (8), then the point encoding (2)
         if (in < 63) { pe_slot(in, it, irow); it += 8; } else in_slot(in - 63, it, irow);
-    } else if (layer == 9) {     // input tiles: bottleneck (8), then the view encoding (1)
-        if (in < 256) in_slot(in, it, irow); else { view_slot(in - 256, it, irow); it += 8; }
+    } else if (layer == 9) {     // input tiles: h7 (8, composed elsewhere), then the view encoding (1)
+        view_slot(in - 256, it, irow);
+        it += 8;
     } else in_slot(in, it, irow);
     const int job = layer;
     const int n_in = a.n_in[job];
     const int reg = (orow & 3) + 4 * (orow >> 3), lane = 32 * ((orow >> 2) & 1) + irow;
-    float v = a.gperm[((size_t)(a.tile0[job] + ot * n_in + it) * 16 + reg) * 64 + lane] * (1.0f / gs);
+    float v = a.gperm[((size_t)(a.tile0[job] + ot * n_in + it) * 16 + reg) * 64 + lane] * inv;
     if (flags) v = __builtin_nanf("");
     float* dst = a.out.g[pi] + e;
     *dst = a.accumulate ? *dst + v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. the two layers around the linear bottleneck
+// ---------------------------------------------------------------------------------------------
+// bott = h7 . W_b + b_b (run_nerf_helpers.py:103) feeds v_pre = [bott, views] . W_v + b_v (:104-110).
+// With P[i][j] = sum over points of h7[i] d v_pre[j] and s[j] = sum of d v_pre[j] (pext rows 0..255 and
+// row 256), and d bott[k] = sum_j W_v[k][j] d v_pre[j]:
+//     dW_b[i][k] = sum_points h7[i] d bott[k]  = sum_j P[i][j] W_v[k][j]          (C1 rows 0..255)
+//     db_b[k]    = sum_points d bott[k]        = sum_j s[j] W_v[k][j]             (C1 row 256)
+//     dW_v[k][j] = sum_points bott[k] d v_pre[j] = sum_i W_b[i][k] P[i][j] + b_b[k] s[j]   (C2), k < 256
+// in fp32 from the fp32 parameters: two products of 257 x 128 x 256 multiply-adds per network and
+// step, one 16 x 16 output tile per workgroup, sums in a fixed order.
+struct ComposeArgs {
+    const float* pext;   // [257][128]
+    const float* w_b;    // bottleneck kernel [256 in][256 out]
+    const float* b_b;    // [256]
+    const float* w_v;    // view layer kernel, rows 0..255: [256][128]
+    float* dw_b;         // [256][256]
+    float* db_b;         // [256]
+    float* dw_v;         // [283][128]: rows 0..255 are written
+    int accumulate;
+};
+constexpr int kComposeC1 = ((kPextRows + 15) / 16) * (256 / 16), kComposeC2 = (256 / 16) * (128 / 16);
+
+__global__ __launch_bounds__(256) void mlp_head_compose_kernel(ComposeArgs a) {
+    __shared__ float As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float sum = 0.f;
+    if ((int)blockIdx.x < kComposeC1) {
+        const int r0 = ((int)blockIdx.x / 16) * 16, k0 = ((int)blockIdx.x % 16) * 16;
+#pragma unroll 1
+        for (int j0 = 0; j0 < kPextCols; j0 += 16) {
+            As[ty][tx] = r0 + ty < kPextRows ? a.pext[(r0 + ty) * kPextCols + j0 + tx] : 0.f;
+            Bs[ty][tx] = a.w_v[(k0 + ty) * 128 + j0 + tx];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sum += As[ty][j] * Bs[tx][j];
+            __syncthreads();
+        }
+        const int r = r0 + ty, k = k0 + tx;
+        if (r > 256) return;
+        float* dst = r < 256 ? a.dw_b + r * 256 + k : a.db_b + k;
+        *dst = a.accumulate ? *dst + sum : sum;
+    } else {
+        const int b = (int)blockIdx.x - kComposeC1;
+        const int k0 = (b / 8) * 16, j0 = (b % 8) * 16;
+#pragma unroll 1
+        for (int i0 = 0; i0 < 256; i0 += 16) {
+            As[ty][tx] = a.w_b[(i0 + ty) * 256 + k0 + tx];
+            Bs[ty][tx] = a.pext[(i0 + ty) * kPextCols + j0 + tx];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += As[i][ty] * Bs[i][tx];
+            __syncthreads();
+        }
+        const int k = k0 + ty, j = j0 + tx;
+        sum += a.b_b[k] * a.pext[256 * kPextCols + j];
+        float* dst = a.dw_v + k * 128 + j;
+        *dst = a.accumulate ? *dst + sum : sum;
+    }
 }
 
 // The jobs of one network, their accumulator tiles in the partial-sum buffer and their share of
@@ -865,8 +962,8 @@ static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs, int* prod_tile
         if (l == 5) add(5, DW_LAYER5, A_H0 + 16 * 4, A_PE, G_DPRE0 + 16 * 5, 0, 16, 8, 11, 0, 16 + 4 + 16);
         else add(l, DW_HIDDEN, A_H0 + 16 * (l - 1), 0, G_DPRE0 + 16 * l, 0, 16, 8, 9, 0, 32);
     }
-    add(8, DW_BOTT_ALPHA, A_H0 + 16 * 7, 0, G_DBOTT, G_DA, 16, 8, 9, 9, 16 + 16 + 2 + 2);   // + alpha: 8 input tiles + bias (+2: the extra product)
-    add(9, DW_VIEW, A_BOTT, A_VPE, G_DV, 0, 8, 4, 10, 0, 16 + 2 + 8);
+    // view layer against [h7 ; view encoding] (the h7 part is P of mlp_head_compose_kernel) + alpha against h7
+    add(9, DW_HEADS, A_H0 + 16 * 7, A_VPE, G_DV, G_DA, 8, 4, 10, 9, 16 + 2 + 8 + 2 + 2);
     add(10, DW_RGB, A_V, 0, G_DC, 0, 1, 1, 5, 0, 8 + 2 + 2);                             // (+2: short stages, unpipelined)
     int tiles = 0, bytes = 0;
     for (int j = 0; j < nj; ++j) {
@@ -876,9 +973,10 @@ static void make_jobs(DwJob* jb, int* total_tiles, int total_wgs, int* prod_tile
         tiles += n_acc[j];
         bytes += blocks[j];
     }
-    if (prod_tile0) {  // alpha rides on the bottleneck job: its row of tiles follows the 8 x 9 main tiles
-        prod_tile0[11] = prod_tile0[8] + 8 * 9;
+    if (prod_tile0) {  // alpha rides on the heads job: its row of tiles follows the 4 x 10 main tiles
+        prod_tile0[11] = prod_tile0[9] + 4 * 10;
         prod_n_in[11] = 9;
+        prod_tile0[8] = -1, prod_n_in[8] = 0;  // the bottleneck's gradient is composed, not accumulated
     }
     *total_tiles = tiles;
     // largest-remainder split of exactly total_wgs workgroups (one more than the CU count would
@@ -916,12 +1014,14 @@ static int dw_workgroups(int64_t wave_tiles, int cus) {
 
 constexpr size_t kTileFloats = 16 * 64;
 
-// Layout of `partial`: status block, summed tiles, then the per-workgroup partial tiles.
+// Layout of `partial`: status block, the operand of mlp_head_compose_kernel, summed tiles, then the
+// per-workgroup partial tiles.
+constexpr size_t kPextBytes = ((size_t)kPextRows * kPextCols * sizeof(float) + 255) / 256 * 256;
 static size_t partial_bytes_for(int wgs) {
     DwJob jb[kNumJobs];
     int tiles, slab;
     make_jobs(jb, &tiles, wgs, nullptr, nullptr, &slab);
-    return kStatusBytes + ((size_t)tiles + slab) * kTileFloats * sizeof(float);
+    return kStatusBytes + kPextBytes + ((size_t)tiles + slab) * kTileFloats * sizeof(float);
 }
 
 }  // namespace nerf
@@ -935,6 +1035,14 @@ NERF_API void nerf_debug_set_stamps(void* p) { g_dw_stamps = (unsigned long long
 
 NERF_API size_t nerf_mlp_packed_bwd_bytes(void) { return layout::kPackedBwdBytes; }
 
+NERF_API int nerf_mlp_train_layout(int32_t* out, int n) {
+    NERF_REQUIRE(out && n >= 10, "nerf_mlp_train_layout: need room for 10 numbers");
+    const int32_t v[10] = {layout::kActBlocks, layout::A_PE, layout::A_H0, layout::A_V, layout::A_VPE, layout::A_MASK,
+                           layout::kGradBlocks, layout::G_DV, layout::G_DPRE0, layout::G_DA};
+    for (int i = 0; i < 10; ++i) out[i] = v[i];
+    return 0;
+}
+
 NERF_API int nerf_mlp_pack_bwd(const float* const* params, void* packed_bwd, nerf_stream_t stream) {
     NERF_REQUIRE(params && packed_bwd, "nerf_mlp_pack_bwd: null pointer");
     NERF_REQUIRE(((uintptr_t)packed_bwd & 15) == 0, "nerf_mlp_pack_bwd: packed_bwd must be 16-byte aligned");
@@ -943,7 +1051,12 @@ NERF_API int nerf_mlp_pack_bwd(const float* const* params, void* packed_bwd, ner
         NERF_REQUIRE(params[i], "nerf_mlp_pack_bwd: params[%d] is null", i);
         pp.p[i] = params[i];
     }
-    mlp_pack_bwd_kernel<<<layout::B_END, 64, 0, as_stream(stream)>>>(pp, (char*)packed_bwd);
+    hipStream_t st = as_stream(stream);
+    for (int i = 16; i <= 18; ++i)
+        NERF_REQUIRE(((uintptr_t)params[i] & 15) == 0, "nerf_mlp_pack_bwd: params[%d] must be 16-byte aligned", i);
+    // the stream, then fp32 copies of what mlp_head_compose_kernel multiplies by (bottleneck kernel
+    // and bias, the first 256 of the view layer's [283][128] rows)
+    mlp_pack_bwd_kernel<<<layout::B_END + kBwdCopyBlocks, 64, 0, st>>>(pp, (char*)packed_bwd);
     return check_launch("nerf_mlp_pack_bwd");
 }
 
@@ -1000,7 +1113,8 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     int tiles, slab_tiles;
     const int wgs = dw_workgroups(da.wave_tiles, cus);
     make_jobs(da.job, &tiles, wgs, ua.tile0, ua.n_in, &slab_tiles);
-    float* gperm = (float*)((char*)partial + kStatusBytes);
+    float* pext = (float*)((char*)partial + kStatusBytes);
+    float* gperm = (float*)((char*)partial + kStatusBytes + kPextBytes);
     da.slabs = gperm + (size_t)tiles * kTileFloats;
     ReduceArgs ra{};
     ra.slabs = da.slabs, ra.gperm = gperm;
@@ -1023,6 +1137,7 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     if (rc) return rc;
 
     ua.gperm = gperm, ua.gscale = gscale > 0.f ? gscale : 0.f, ua.status = status, ua.accumulate = accumulate;
+    ua.pext = pext;
     static const int dims[12][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
                                     {256, 256}, {256, 256}, {256, 256}, {283, 128}, {128, 3}, {256, 1}};
     ua.first[0] = 0;
@@ -1030,8 +1145,14 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
         const int in_dim = dims[i >> 1][0], out_dim = dims[i >> 1][1];
         ua.first[i + 1] = ua.first[i] + ((i & 1) ? out_dim : in_dim * out_dim);
     }
-    mlp_grad_unpack_kernel<<<(ua.first[24] + 255) / 256, 256, 0, st>>>(ua);
-    return check_launch("nerf_mlp_backward(unpack)");
+    mlp_grad_unpack_kernel<<<(ua.first[24] + kPextRows * kPextCols + 255) / 256, 256, 0, st>>>(ua);
+    rc = check_launch("nerf_mlp_backward(unpack)");
+    if (rc) return rc;
+    const char* pb = (const char*)packed_bwd;
+    ComposeArgs co{pext, (const float*)(pb + layout::kBwdBottW), (const float*)(pb + layout::kBwdBottB),
+                   (const float*)(pb + layout::kBwdViewW), grads[16], grads[17], grads[18], accumulate};
+    mlp_head_compose_kernel<<<kComposeC1 + kComposeC2, 256, 0, st>>>(co);
+    return check_launch("nerf_mlp_backward(compose)");
 }
 
 NERF_API int nerf_mlp_backward_status(const void* partial, int* flags, float* gscale_used, float* absmax_d_raw,

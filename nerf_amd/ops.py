@@ -320,6 +320,14 @@ def act_bytes(n_points):
     return int(nv.lib().nerf_mlp_act_bytes(int(n_points)))
 
 
+def train_layout():
+    """Block numbers of the saved training tensors (nerf_mlp_train_layout), as a dict."""
+    out = (ctypes.c_int32 * 10)()
+    nv.check(nv.lib().nerf_mlp_train_layout(out, 10), "nerf_mlp_train_layout")
+    names = ("act_blocks", "pe", "h0", "v", "vpe", "mask", "grad_blocks", "d_v", "d_pre0", "d_alpha")
+    return dict(zip(names, (int(x) for x in out)))
+
+
 def mlp_forward_train(packed, rays, z, act):
     """mlp_forward_rays that also fills `act` (uint8 [act_bytes(N*S)]) for the backward pass."""
     n, width = rays.shape

@@ -64,8 +64,9 @@ def test_forward_train_matches_inference_and_saves_activations(gpu):
     # the saving forward is the inference kernel plus stores: same bits
     assert torch.equal(raw_t, raw_i)
     # decode the saved h7 of the first wave tile (points 0..31) and compare with the oracle
-    blk = act.view(-1, 167, 1024)[0]
-    h7 = blk[4 + 16 * 7: 4 + 16 * 8].contiguous().view(torch.float16).view(16, 64, 8).float().cpu().numpy()
+    lay = ops.train_layout()
+    blk = act.view(-1, lay['act_blocks'], 1024)[0]
+    h7 = blk[lay['h0'] + 16 * 7: lay['h0'] + 16 * 8].contiguous().view(torch.float16).view(16, 64, 8).float().cpu().numpy()
     zz = z.cpu().numpy().astype(np.float64)
     r = rb.astype(np.float64)
     pts = (r[:, None, 0:3] + r[:, None, 3:6] * zz[:, :, None]).reshape(-1, 3)[:32]
@@ -87,7 +88,7 @@ def test_forward_train_matches_inference_and_saves_activations(gpu):
                 assert abs(h7[b, lane, j] - hcur[c, f]) < 2e-3 * max(1., abs(hcur[c, f])), (b, lane, j)
     # the mask block of h7: with i = 2 t + (r >> 1), bit (i & 15) + 16 (r & 1) of dword [pt][i >> 4] of
     # lane (point, g) = unit 16 t + 4 g + r
-    mk = blk[158 + 7].contiguous().view(torch.int32).view(64, 4).cpu().numpy().astype(np.uint32)
+    mk = blk[lay['mask'] + 7].contiguous().view(torch.int32).view(64, 4).cpu().numpy().astype(np.uint32)
     for lane in range(64):
         g = lane >> 4
         for pt in range(2):
@@ -125,9 +126,11 @@ def _mlp_grads_reference(ws, rb, z, d_raw, act):
     one arithmetic and off in the other; its gradient is then all or nothing.  The backward pass
     must follow the forward pass it belongs to, so the reference takes the on/off pattern from
     the activations the GPU forward saved and differentiates pre * mask instead of relu(pre)."""
+    from nerf_amd import ops
     n_points = z.size
-    masks = [torch.tensor(_decode_blocks(act, 167, 4 + 16 * l, 16, n_points) != 0) for l in range(8)]
-    mask_v = torch.tensor(_decode_blocks(act, 167, 148, 8, n_points) != 0)
+    lay = ops.train_layout()
+    masks = [torch.tensor(_decode_blocks(act, lay['act_blocks'], lay['h0'] + 16 * l, 16, n_points) != 0) for l in range(8)]
+    mask_v = torch.tensor(_decode_blocks(act, lay['act_blocks'], lay['v'], 8, n_points) != 0)
     W = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws]
     r = torch.tensor(rb, dtype=torch.float64)
     zz = torch.tensor(z, dtype=torch.float64)
