@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs GPU steps one after another on the box: "name|seconds|command" per argument.  A step that
-# ends with anything but 0 (ok) or 1 (a test assertion failed) stops the chain: after a fault, an
-# abort or a time limit nothing more is started on the GPU in the same call.
+# ends with anything but 0 stops the chain: after a fault, an abort, a time limit or a failed test
+# (which a GPU fault can look like) nothing more is started on the GPU in the same call.
 mkdir -p gpurun_out
 for spec in "$@"; do
   name="${spec%%|*}"; rest="${spec#*|}"; secs="${rest%%|*}"; cmd="${rest#*|}"
@@ -9,5 +9,5 @@ for spec in "$@"; do
   rc=$?
   echo "[$name] rc=$rc"
   tail -n 4 "gpurun_out/$name.log"
-  if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "stopping after $name (rc=$rc)"; exit $rc; fi
+  if [ $rc -ne 0 ]; then echo "stopping after $name (rc=$rc)"; exit $rc; fi
 done
