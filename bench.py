@@ -291,8 +291,9 @@ def main():
     from nerf_amd import ops, parallel
     from nerf_amd.run_nerf import create_nerf, render
 
-    torch.manual_seed(0)  # identical replicas of both networks on every rank
+    torch.manual_seed(rank)  # every rank draws its own initial weights; create_nerf broadcasts rank 0's
     kw_train, kw_test, _, _, models = create_nerf(make_args())
+    parallel.seed_sampling(0)  # per-rank streams for the stratified depths and resampling uniforms
     o, d = synthetic_batch(a.rays, 1000 + rank, dev)
     def step():
         rgb, disp, acc, _ = render(1, 1, 1., chunk=a.chunk, rays=(o, d), near=2., far=6., **kw_test)

@@ -175,7 +175,10 @@ int nerf_render_rays(const void* packed_coarse, const void* packed_fine, const f
  * library runs on holds until the process ends; a call whose
  * nerf_render_rays_workspace_bytes(n_rays, N_samples, N_importance) exceeds it is rejected with
  * NERF_E_UNSUPPORTED before anything is launched (about 12,000 rays at 64 + 128 samples).  The call
- * allocates and frees nothing.  All calls on one GPU share the array: calls that overlap in time on
+ * allocates and frees nothing.  The first call on a GPU looks the array's address up, which makes
+ * the HIP runtime load the code object that holds it on that GPU (the GPU's free memory drops by
+ * the array's size at that moment, once); a call with n_rays == 0 does just that set-up, for
+ * callers that want it out of the way before they start capturing or serving.  All calls on one GPU share the array: calls that overlap in time on
  * one GPU (different streams or threads) race; calls on one stream, or on different GPUs, do not. */
 size_t nerf_render_rays_static_bytes(void);
 int nerf_render_rays_static(const void* packed_coarse, const void* packed_fine, const float* rays, int width,
@@ -230,9 +233,11 @@ size_t nerf_mlp_partial_bytes(void);
  * to one network): d_raw [n_points,4] -> grads: HOST array of 24 device pointers in get_weights()
  * order, each shaped like its parameter.  `act` is what nerf_mlp_forward_train saved for the same
  * points.  The chain runs in fp16 with fp32 accumulation; d_raw is multiplied by a power of two
- * first and the result divided by it.  gscale <= 0 (the normal use): the factor is formed on the
+ * first and the result divided by it.  gscale == 0 (the normal use): the factor is formed on the
  * device from max|d_raw| so that the largest scaled element lies in [256, 512) -- no host
- * synchronisation.  gscale > 0: the caller's factor is used as given.  Either way the call records
+ * synchronisation.  gscale < 0: the same with the target [-gscale, -2 gscale), -gscale a power of
+ * two in [2^-14, 2^14] (lower it for networks that amplify gradients by more than the 128x of
+ * headroom the default leaves).  gscale > 0: the caller's factor is used as given.  Either way the call records
  * whether a layer gradient saturated the fp16 range (or was not finite) or everything sank below
  * the smallest normal fp16; when either happened the gradients are written as NaN, never as
  * plausible numbers (read the bits with nerf_mlp_backward_status).
@@ -259,7 +264,9 @@ int nerf_mse_loss_fwd_bwd(const float* x, const float* y, int64_t count, float i
 
 /* tf.keras.optimizers.Adam dense update (run_nerf.py:605,:826) over a flat buffer of n scalars:
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr_t m/(sqrt(v)+eps), where the caller
- * passes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (eps is not bias-corrected, as in Keras). */
+ * passes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (eps is not bias-corrected, as in Keras).  Elements whose
+ * gradient is NaN or infinite are skipped (parameter and moments unchanged): nerf_mlp_backward
+ * writes NaN gradients when its fp16 chain saturated, and such a step must not reach the weights. */
 int nerf_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, float lr_t,
                    float beta1, float beta2, float eps, nerf_stream_t stream);
 

@@ -29,11 +29,13 @@
 // The gradient scale.  The chain carries gradients in fp16, so d raw is multiplied by a power of
 // two on entry and the result divided by it on exit.  By default the factor is formed on the
 // device from max |d raw| (draw_absmax_kernel) so that the largest scaled element lies in
-// [256, 512): 128x of headroom to the fp16 maximum for growth inside the chain, 2^22 of range
-// below it before the smallest normal number.  The weight-gradient kernel, which reads every stored
-// layer gradient anyway, records the largest fp16 bit pattern it saw; the unpack kernel turns that
-// into a status word (saturated / non-finite, or everything below the smallest normal number) and,
-// when it is set, writes NaN instead of numbers nobody should trust.
+// [T, 2T) for a power of two T the caller chooses (256 unless told otherwise: 128x of headroom to
+// the fp16 maximum for growth inside the chain, 2^22 of range below it before the smallest normal
+// number, which is what the many small entries of d raw -- samples of little weight -- need; a
+// caller whose networks amplify gradients more lowers T).  The weight-gradient kernel, which reads
+// every stored layer gradient anyway, records the largest fp16 bit pattern it saw; the unpack
+// kernel turns that into a status word (saturated / non-finite, or everything below the smallest
+// normal number) and, when it is set, writes NaN instead of numbers nobody should trust.
 #include "mlp_common.h"
 #include "mlp_layout_wide.h"
 
@@ -52,11 +54,12 @@ enum StatusWord {
     ST_YMAX_OUT = 7,    // out: copy of ST_YMAX
 };
 
-// The power of two that brings mx into [256, 512); 1 when mx is zero, denormal or not finite.
-__host__ __device__ inline float auto_gscale(unsigned absmax_bits) {
+// The power of two that brings mx into [2^target_exp, 2^(target_exp+1)); 1 when mx is zero,
+// denormal or not finite.
+__host__ __device__ inline float auto_gscale(unsigned absmax_bits, int target_exp) {
     const int e = (int)((absmax_bits >> 23) & 0xffu);
     if (e == 0 || e == 255) return 1.0f;
-    int f = 127 + 8 - (e - 127);
+    int f = 127 + target_exp - (e - 127);
     f = f < 1 ? 1 : f > 254 ? 254 : f;
     const unsigned bits = (unsigned)f << 23;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -209,6 +212,7 @@ struct ChainArgs {
     char* gbuf;           // [wave tiles][kGradBlocks][1 KiB]
     int64_t M;
     float gscale;         // > 0: the caller's factor; otherwise formed from status[ST_ABSMAX]
+    int target_exp;       // ... so that the largest scaled element lies in [2^target_exp, 2^(target_exp+1))
     const unsigned* status;
 };
 
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_chain_kernel(ChainArgs a) {
     if (p < a.M && h == 0) g = a.d_raw[p];
     half8 dC = {0, 0, 0, 0, 0, 0, 0, 0}, dA = {0, 0, 0, 0, 0, 0, 0, 0};
     {
-        const float gs = a.gscale > 0.f ? a.gscale : auto_gscale(a.status[ST_ABSMAX]);
+        const float gs = a.gscale > 0.f ? a.gscale : auto_gscale(a.status[ST_ABSMAX], a.target_exp);
         // saturating conversions (a NaN stays a NaN and is reported by the status word)
         const half2v xy = __builtin_convertvector(f32x2{g.x * gs, g.y * gs}, half2v);
         const half2v zw = __builtin_convertvector(f32x2{g.z * gs, g.w * gs}, half2v);
@@ -776,6 +780,7 @@ struct UnpackArgs {
     const float* gperm;
     GradPtrs out;
     float gscale;      // > 0: the caller's factor; otherwise the one formed from status[ST_ABSMAX]
+    int target_exp;
     unsigned* status;
     int accumulate;
     int tile0[kNumProducts];  // per product (0..7 point layers, 8 bottleneck: none, 9 view, 10 rgb, 11 alpha):
@@ -825,7 +830,7 @@ __device__ __forceinline__ void view_slot(int f, int& tile, int& row) {
 __global__ void mlp_grad_unpack_kernel(UnpackArgs a) {
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned absmax = a.status[ST_ABSMAX], ymax = a.status[ST_YMAX];
-    const float gs = a.gscale > 0.f ? a.gscale : auto_gscale(absmax);
+    const float gs = a.gscale > 0.f ? a.gscale : auto_gscale(absmax, a.target_exp);
     // saturated (the chain clamps at the largest finite fp16, 0x7bff), infinite or NaN; or, with a
     // non-zero d raw, not one stored gradient as large as the smallest normal fp16 (0x0400)
     unsigned flags = 0u;
@@ -1077,7 +1082,16 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
                                float* const* grads, int accumulate, nerf_stream_t stream) {
     NERF_REQUIRE(packed_bwd && act && d_raw && gbuf && partial && grads, "nerf_mlp_backward: null pointer");
     NERF_REQUIRE(n_points >= 0, "nerf_mlp_backward: bad size");
-    NERF_REQUIRE(gscale == gscale && gscale < 3.0e38f, "nerf_mlp_backward: gscale must be finite (<= 0 selects the automatic scale)");
+    NERF_REQUIRE(gscale == gscale && gscale < 3.0e38f && gscale > -3.0e38f, "nerf_mlp_backward: gscale must be finite (<= 0 selects the automatic scale)");
+    // gscale < 0: automatic, with the largest scaled element in [-gscale, -2 gscale)
+    int target_exp = 8;
+    if (gscale < 0.f) {
+        int e2 = 0;
+        const float mant = frexpf(-gscale, &e2);  // -gscale = mant * 2^e2, mant in [0.5, 1)
+        NERF_REQUIRE(mant == 0.5f && e2 - 1 >= -14 && e2 - 1 <= 14,
+                     "nerf_mlp_backward: a negative gscale names the target of the automatic scale, a power of two in [2^-14, 2^14] (got %g)", (double)-gscale);
+        target_exp = e2 - 1;
+    }
     NERF_REQUIRE((((uintptr_t)packed_bwd | (uintptr_t)act | (uintptr_t)d_raw | (uintptr_t)gbuf | (uintptr_t)partial) & 15) == 0,
                  "nerf_mlp_backward: buffers must be 16-byte aligned");
     UnpackArgs ua{};
@@ -1102,7 +1116,7 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
         if (rc) return rc;
     }
     ChainArgs ca{(const char*)packed_bwd, (const char*)act, (const float4*)d_raw, (char*)gbuf, n_points,
-                 gscale > 0.f ? gscale : 0.f, status};
+                 gscale > 0.f ? gscale : 0.f, target_exp, status};
     mlp_bwd_chain_kernel<<<(unsigned)blocks, 512, 0, st>>>(ca);
     int rc = check_launch("nerf_mlp_backward(chain)");
     if (rc) return rc;
@@ -1136,7 +1150,7 @@ NERF_API int nerf_mlp_backward(const void* packed_bwd, const void* act, const fl
     rc = check_launch("nerf_mlp_backward(reduce)");
     if (rc) return rc;
 
-    ua.gperm = gperm, ua.gscale = gscale > 0.f ? gscale : 0.f, ua.status = status, ua.accumulate = accumulate;
+    ua.gperm = gperm, ua.gscale = gscale > 0.f ? gscale : 0.f, ua.target_exp = target_exp, ua.status = status, ua.accumulate = accumulate;
     ua.pext = pext;
     static const int dims[12][2] = {{63, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
                                     {256, 256}, {256, 256}, {256, 256}, {283, 128}, {128, 3}, {256, 1}};

@@ -134,7 +134,12 @@ NERF_API int nerf_render_rays_static(const void* packed_coarse, const void* pack
                                      float* z_std, nerf_stream_t stream) {
     int rc = check_render_args("nerf_render_rays_static", packed_coarse, rays, width, n_rays, N_samples, N_importance, rgb_map);
     if (rc) return rc;
-    if (n_rays == 0) return 0;
+    if (n_rays == 0) {
+        // set-up only: the code object that holds the array is loaded on the current device now (the
+        // device's free memory drops by the array's size here, once, and by nothing in later calls)
+        char* ws = nullptr;
+        return static_scratch(&ws);
+    }
     const size_t need = nerf_render_rays_workspace_bytes(n_rays, N_samples, N_importance);
     if (need > kStaticScratchBytes)
         return NERF_FAIL(NERF_E_UNSUPPORTED,

@@ -29,12 +29,16 @@ __global__ __launch_bounds__(256) void mse_fwd_bwd_kernel(const float* __restric
 
 // tf.keras.optimizers.Adam, dense update (non-amsgrad), with lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
 // formed on the host:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  theta -= lr_t m/(sqrt(v)+eps).
+// An element whose gradient is not finite is left as it is, moments included: the backward pass
+// writes NaN for a whole network when its fp16 gradient chain saturated, and that step is then
+// skipped for the network instead of putting NaN into its weights and moments for good.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float lr_t, float b1, float b2, float eps) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i];
+    if (!(fabsf(gi) <= 3.0e38f)) return;
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * (gi * gi);
     m[i] = mi;

@@ -41,23 +41,6 @@ def pose_spherical(theta, phi, radius):
     return _BLENDER_AXES @ c2w
 
 
-def linemod_dpt(path):
-    """load_blender.py:42-51: int32 rows, int32 cols, then uint16 millimetres -> metres."""
-    with open(path, 'rb') as fp:
-        rows, cols = np.frombuffer(fp.read(8), dtype=np.int32)
-        return (np.frombuffer(fp.read(), dtype=np.uint16).reshape(rows, cols) / 1000.).astype(np.float32)
-
-
-def smooth_kinect_depth(depth_raw):
-    """load_blender.py:54-68: invalid readings (0 or 65535) take the nearest valid one."""
-    import scipy.interpolate
-    depth = depth_raw / 1000.
-    bad = (depth_raw == 2 ** 16 - 1) | (depth_raw == 0)
-    yy, xx = np.mgrid[0:depth_raw.shape[0], 0:depth_raw.shape[1]]
-    filled = scipy.interpolate.griddata((xx[~bad], yy[~bad]), depth[~bad].ravel(), (xx, yy), method='nearest')
-    return filled.astype(np.float32)
-
-
 def area_halve(imgs):
     """Area resampling to half resolution: the mean of each 2x2 block (what
     tf.image.resize_area computes for an exact factor of two, load_blender.py:164)."""
@@ -73,13 +56,17 @@ def load_blender_data(basedir, half_res=False, testskip=1, image_extn='.png', ge
     """load_blender.py:71-178.  The reference resizes to a hard-coded 400x400 when half_res is
     set (:164) while halving H and W (:165-166); here the images are halved, which is the same
     thing for the 800x800 data the flag exists for."""
+    if get_depths:
+        raise NotImplementedError("load_blender_data(get_depths=True): depth maps feed the fork's LINEMOD depth loss "
+                                  "(run_nerf.py:715-729, :816-823; load_blender.py:42-68, :112-121), which is not part "
+                                  "of this build; the depth file names are still returned in extras['depth_filenames']")
     splits = ['train', 'val', 'test']
     metas = {}
     for s in splits:
         with open(os.path.join(basedir, f'transforms_{s}.json'), 'r') as fp:
             metas[s] = json.load(fp)
 
-    all_imgs, all_poses, all_depths, all_files, all_depth_files = [], [], [], [], []
+    all_imgs, all_poses, all_files, all_depth_files = [], [], [], []
     counts = [0]
     for s in splits:
         meta = metas[s]
@@ -89,7 +76,7 @@ def load_blender_data(basedir, half_res=False, testskip=1, image_extn='.png', ge
                 raise KeyError(f"frames_field '{field}' not in transforms_{s}.json (has {list(meta.keys())})")
         else:
             picked, field = slice(None, test_finish, testskip), 'frames'
-        imgs, poses, depths, files, depth_files = [], [], [], [], []
+        imgs, poses, files, depth_files = [], [], [], []
         for frame in meta[field][picked]:
             name = frame[image_field]
             path = os.path.join(basedir, name if any(e in name for e in ('png', 'jpg')) else name + image_extn)
@@ -103,18 +90,9 @@ def load_blender_data(basedir, half_res=False, testskip=1, image_extn='.png', ge
             if 'depth_path' in frame:
                 dpath = frame['depth_path']
                 depth_files.append(dpath)
-                if get_depths:
-                    if not os.path.isfile(dpath):
-                        raise FileNotFoundError(f"depth map not found: {dpath}")
-                    if '.png' in dpath:
-                        raw = imread(dpath)
-                        depths.append(smooth_kinect_depth(raw) if s == 'train' else raw / 1000.)
-                    elif '.dpt' in dpath:
-                        depths.append(linemod_dpt(dpath))
         all_imgs.append((np.array(imgs) / 255.).astype(np.float32))   # all channels kept (RGBA)
         all_poses.append(np.array(poses).astype(np.float32))
         counts.append(counts[-1] + len(imgs))
-        all_depths.append(depths)
         all_files.append(files)
         all_depth_files.append(depth_files)
 
@@ -133,8 +111,6 @@ def load_blender_data(basedir, half_res=False, testskip=1, image_extn='.png', ge
     if half_res:
         imgs = area_halve(imgs)
         H, W, focal = H // 2, W // 2, focal / 2.
-    if get_depths:
-        extras['depth_maps'] = np.stack([d for ds in all_depths for d in ds], axis=0)
     if 'K' in meta:
         extras['K'] = np.array(meta['K'], dtype=np.float32)
     extras['filenames'] = all_files

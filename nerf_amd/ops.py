@@ -276,7 +276,10 @@ def resample_merge(z_vals, weights, N_importance, det=True, u=None, want_samples
     return z_out, z_samples, z_std
 
 
-_RENDER_WS = {}  # device -> grow-only workspace of render_rays_single_call
+# (device, stream) -> grow-only workspace of render_rays_single_call.  One per stream: calls on
+# different streams of one GPU may overlap and must not share intermediates; a workspace that is
+# outgrown is only dropped by the stream that used it, behind the work that stream has queued.
+_RENDER_WS = {}
 
 
 def render_rays_single_call(packed_coarse, packed_fine, rays, N_samples, N_importance, lindisp=False,
@@ -286,9 +289,11 @@ def render_rays_single_call(packed_coarse, packed_fine, rays, N_samples, N_impor
     n, width = rays.shape
     dev = rays.device
     need = int(nv.lib().nerf_render_rays_workspace_bytes(n, int(N_samples), int(N_importance)))
-    ws = _RENDER_WS.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _RENDER_WS.get(key)
     if ws is None or ws.numel() < need:
-        ws = _RENDER_WS[dev] = torch.empty((max(need, 1),), dtype=torch.uint8, device=dev)
+        ws = _RENDER_WS[key] = torch.empty((max(need, 1),), dtype=torch.uint8, device=dev)
+        ws.record_stream(torch.cuda.current_stream(dev))
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     ret = dict(rgb_map=new(n, 3), disp_map=new(n), acc_map=new(n), depth_map=new(n))
     if N_importance > 0:
@@ -374,8 +379,9 @@ def mlp_backward_status(partial):
 
 def mlp_backward(packed_bwd, act, d_raw, gscale, gbuf, partial, grads, accumulate=False):
     """Parameter gradients (24 tensors shaped like the parameters, written in place) from
-    d_raw [N,S,4] and the activations saved by mlp_forward_train.  gscale None or <= 0: the
-    fp16 gradient scale is formed on the device from max|d_raw|."""
+    d_raw [N,S,4] and the activations saved by mlp_forward_train.  gscale None or 0: the fp16
+    gradient scale is formed on the device from max|d_raw| (largest scaled element in [256, 512));
+    gscale < 0: the same with the target [-gscale, -2 gscale), a power of two; > 0: used as given."""
     gscale = 0.0 if gscale is None else gscale
     n_points = d_raw.numel() // 4
     if gbuf.numel() < grad_bytes(n_points) or partial.numel() < partial_bytes():

@@ -77,6 +77,51 @@ def render_sharded(render_flat_fn, rays_flat, keys=('rgb_map', 'disp_map', 'acc_
     return res
 
 
+def gather_dict(local, n_total):
+    """All-gathers a dict of per-ray tensors [n_local, ...] into full-length ones with ONE
+    collective: the entries are packed side by side into a single [n_local, C] fp32 tensor."""
+    keys = sorted(local)
+    cols = [local[k].reshape(local[k].shape[0], -1).to(torch.float32) for k in keys]
+    widths = [c.shape[1] for c in cols]
+    full = gather_rows(torch.cat(cols, 1), n_total)
+    res, at = {}, 0
+    for k, wd in zip(keys, widths):
+        res[k] = full[:, at:at + wd].reshape((n_total,) + tuple(local[k].shape[1:]))
+        at += wd
+    return res
+
+
+def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, **kwargs):
+    """run_nerf.render (run_nerf.py:28-119) with the ray batch sharded over the ranks: every rank
+    must make the same call (same camera or same ray batch); each renders its contiguous slice and
+    all of them return the complete [rgb_map, disp_map, acc_map, extras].  render_path takes it
+    through its render_kwargs: render_path(poses, hwf, chunk, dict(render_kwargs_test,
+    shard_over_ranks=True))."""
+    from .run_nerf import render as render_one
+    return render_one(H, W, focal, chunk=chunk, rays=rays, c2w=c2w, shard_over_ranks=True, **kwargs)
+
+
+def seed_sampling(seed):
+    """Seeds this rank's random streams (stratified depths, resampling uniforms, density noise,
+    drawn with torch.rand / torch.randn on the GPU) with seed + rank, so that data-parallel ranks
+    jitter their shards independently.  Network weights are not affected: create_nerf broadcasts
+    rank 0's."""
+    r, _ = world()
+    torch.manual_seed(int(seed) + r)
+
+
+def broadcast_int(value, src=0):
+    """The integer `value` of rank `src` on every rank (e.g. the step a run resumes from)."""
+    _, w = world()
+    if w == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def global_count(n_local, device=None):
     """Sum of `n_local` over the ranks (the global ray count of a sharded batch) as a 0-d float64
     tensor on `device`: one tiny collective and no host synchronisation (the optimisation loop must
@@ -113,7 +158,10 @@ class _Done:
 def broadcast_parameters(models, src=0):
     """Makes every rank's networks bit-identical replicas of rank `src`'s (one broadcast of the
     flat parameter buffer per network), e.g. after create_nerf drew the initial weights from each
-    rank's own generator or only one rank found a checkpoint."""
+    rank's own generator or only one rank found a checkpoint.  create_nerf broadcasts the step to
+    resume from as well (broadcast_int); the optimiser is created after it with zero moments and
+    iteration 0 on every rank -- the reference never reloads its state (run_nerf.py:244-261) --
+    so nothing of it needs to travel."""
     _, w = world()
     if w == 1:
         return

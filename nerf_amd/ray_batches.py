@@ -46,7 +46,7 @@ class RayBatcher:
     """
 
     def __init__(self, H, W, focal, poses, images, i_train, N_rand, use_batching=True,
-                 precrop_iters=0, precrop_frac=0.5, device=None, seed=None):
+                 precrop_iters=0, precrop_frac=0.5, device=None, seed=None, rank=0, world_size=1):
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         dev = ops._dev() if device is None else torch.device(device)
         self.device = dev
@@ -62,6 +62,15 @@ class RayBatcher:
         self.N_rand = int(N_rand)
         self.use_batching = bool(use_batching)
         self.precrop_iters, self.precrop_frac = int(precrop_iters), float(precrop_frac)
+        # Data parallel: N_rand is the GLOBAL batch.  Every rank draws the same permutation / image
+        # / pixel selection from the same seed and keeps its contiguous slice of the N_rand picks
+        # (parallel.shard_bounds), so the ranks' shards are disjoint and together are exactly the
+        # batch one process would have drawn.
+        self.rank, self.world_size = int(rank), int(world_size)
+        if not 0 <= self.rank < self.world_size:
+            raise ValueError(f"RayBatcher: rank {rank} outside world of {world_size}")
+        if self.world_size > 1 and seed is None:
+            raise ValueError("RayBatcher: data-parallel ranks need a common seed to draw the same global batch")
         self.gen = torch.Generator(device=dev)
         self.host_gen = torch.Generator()  # the image of a step is drawn on the host: no device round trip
         if seed is not None:
@@ -85,11 +94,19 @@ class RayBatcher:
     def _pooled(self):
         if self.perm is None or self.i_batch >= self.n_rays:
             self.shuffle()
-        ids = self.perm[self.i_batch:self.i_batch + self.N_rand]
+        ids = self._mine(self.perm[self.i_batch:self.i_batch + self.N_rand])
         self.i_batch += self.N_rand
         hw = self.H * self.W
         return ops.gather_pixel_rays(self.H, self.W, self.focal, self.poses, self.images,
                                      torch.div(ids, hw, rounding_mode='floor'), ids % hw)
+
+    def _mine(self, picks):
+        """This rank's contiguous slice of a global batch of picks."""
+        if self.world_size == 1:
+            return picks
+        from .parallel import shard_bounds
+        lo, hi = shard_bounds(int(picks.shape[0]), self.rank, self.world_size)
+        return picks[lo:hi]
 
     # -- one image per step ------------------------------------------------------------------
     def _single(self, i, image=None, select=None):
@@ -101,7 +118,7 @@ class RayBatcher:
             pix = self._window_ids[window] = torch.as_tensor(window_pixels(self.H, self.W, window), device=self.device)
         if select is None:
             select = torch.randperm(pix.numel(), device=self.device, generator=self.gen)[:self.N_rand]
-        pix = pix[torch.as_tensor(select, device=self.device).to(torch.int64)]
+        pix = pix[self._mine(torch.as_tensor(select, device=self.device).to(torch.int64))]
         return ops.gather_pixel_rays(self.H, self.W, self.focal, self.poses, self.images,
                                      torch.full_like(pix, image), pix)
 

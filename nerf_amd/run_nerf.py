@@ -29,9 +29,13 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
 
 
 def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1.,
-           use_viewdirs=False, c2w_staticcam=None, **kwargs):
+           use_viewdirs=False, c2w_staticcam=None, shard_over_ranks=False, **kwargs):
     """run_nerf.py:28-119.  Returns [rgb_map, disp_map, acc_map, extras] with the leading shape of
-    the rays ([H,W] for a camera, [B] for a ray batch)."""
+    the rays ([H,W] for a camera, [B] for a ray batch).
+
+    shard_over_ranks (not in the reference): under torch.distributed every rank must then make
+    the same call; each renders a contiguous slice of the flat ray batch and one all-gather hands
+    every rank the complete outputs (nerf_amd.parallel.render)."""
     if c2w is not None:
         if 'K' in kwargs:
             raise NotImplementedError("render(K=...): intrinsics-matrix rays (NERFCO.get_rays_tf_K, "
@@ -56,7 +60,16 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     sh = rays_d.shape                                                                 # :91
     rays_flat = ops.build_ray_batch(rays_o, rays_d, view_src, ndc, H, W, focal, near, far)  # :92-108
 
-    all_ret = batchify_rays(rays_flat, chunk, **kwargs_copy)                          # :111
+    from . import parallel
+    rank, world_size = parallel.world()
+    if shard_over_ranks and world_size > 1:
+        n_all = rays_flat.shape[0]
+        lo, hi = parallel.shard_bounds(n_all, rank, world_size)
+        per_ray = ('perturb_u', 'pdf_u', 'noise0', 'noise1')
+        kw = {k: (v[lo:hi] if (k in per_ray and v is not None) else v) for k, v in kwargs_copy.items()}
+        all_ret = parallel.gather_dict(batchify_rays(rays_flat[lo:hi], chunk, **kw), n_all)
+    else:
+        all_ret = batchify_rays(rays_flat, chunk, **kwargs_copy)                      # :111
     for k in all_ret:
         k_sh = list(sh[:-1]) + list(all_ret[k].shape[1:])                             # :113
         all_ret[k] = torch.reshape(all_ret[k], k_sh)
@@ -172,7 +185,9 @@ def create_nerf(args):
             ft_weights_fine = '{}_fine_{}'.format(ft_weights[:-11], ft_weights[-10:])
             print('Reloading fine from', ft_weights_fine)
             model_fine.set_weights(load_weights(ft_weights_fine))
-    # one process per GPU: every rank must hold the same replicas (each drew its own initial weights)
+    # one process per GPU: every rank must hold the same replicas (each drew its own initial
+    # weights, and perhaps only some found a checkpoint) and resume from the same step
     from . import parallel
     parallel.broadcast_parameters(models.values())
+    start = parallel.broadcast_int(start)
     return render_kwargs_train, render_kwargs_test, start, grad_vars, models

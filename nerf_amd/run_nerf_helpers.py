@@ -129,8 +129,14 @@ class NerfModel:
         self._packed_bwd_version = None
         self._epoch = 0          # bumped by updates that bypass torch (the fused Adam kernel)
         # factor applied to d_raw before the fp16 gradient chain; None = formed on the device from
-        # max|d_raw| at every backward pass (what callers should leave it at)
+        # max|d_raw| at every backward pass (what callers should leave it at) so that the largest
+        # scaled element lies in [auto_target, 2 auto_target).  auto_target is lowered by itself
+        # when a backward pass reports saturation (review_grad_status)
         self.grad_scale = None
+        self.auto_target = 256.0
+        self._status_ring = None   # two pinned host copies of the status block + their events
+        self._status_n = 0
+        self._clean_reviews = 0
         self._grad_partial = None  # scratch of the last backward pass; its head is the status block
         self._grad_flat = None     # flat gradient buffer of the last backward pass (24 views tile it)
         self._grad_work = None     # pending all-reduce of that buffer under data parallelism
@@ -195,6 +201,41 @@ class NerfModel:
         if self._grad_partial is None:
             return 0, 0.0, 0.0
         return ops.mlp_backward_status(self._grad_partial)
+
+    # The automatic gradient scale looks after itself, the way dynamic loss scaling does: every
+    # backward pass leaves its status block in a pinned host buffer (asynchronous copy, no wait),
+    # and the pass after the next one reads it.  A saturated pass produced NaN gradients, which
+    # the Adam kernel skipped; the target is then lowered 16-fold for the following passes.  An
+    # underflow raises it 16-fold; 1000 sound passes in a row raise it two-fold, up to 256.  The
+    # two-pass delay keeps the host from ever waiting for the pass the GPU is still working on.
+    def post_grad_status(self):
+        if self._grad_partial is None or not self._grad_partial.is_cuda:
+            return
+        if self._status_ring is None:
+            self._status_ring = [(torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        host, event = self._status_ring[self._status_n % 2]
+        host.copy_(self._grad_partial[:32].view(torch.int32), non_blocking=True)
+        event.record()
+        self._status_n += 1
+
+    def review_grad_status(self):
+        """Adjusts auto_target from the status of the backward pass before the last one."""
+        if self._status_ring is None or self._status_n < 2 or self.grad_scale is not None:
+            return
+        host, event = self._status_ring[self._status_n % 2]   # the older of the two
+        event.synchronize()
+        flags = int(host[4])
+        if flags & ops.GRAD_SATURATED:
+            self.auto_target = max(self.auto_target / 16.0, 2.0 ** -8)
+            self._clean_reviews = 0
+        elif flags & ops.GRAD_UNDERFLOW:
+            self.auto_target = min(self.auto_target * 16.0, 2.0 ** 12)
+            self._clean_reviews = 0
+        else:
+            self._clean_reviews += 1
+            if self._clean_reviews >= 1000 and self.auto_target < 256.0:
+                self.auto_target *= 2.0
+                self._clean_reviews = 0
 
     def mark_dirty(self):
         """Call after writing the parameters behind torch's back (raw kernels on self.flat)."""

@@ -27,6 +27,8 @@ from . import parallel
 
 _TAPE_DEPTH = 0
 _TAPE_EPOCH = 0   # bumped when a tape opens: a network's reusable gradient buffer is handed out once per tape
+_DP_STEP = None   # set by train_step around tape.gradient: the data-parallel exchange the backward nodes start
+_TAIL = 2         # floats behind a network's flat gradient: [n_local * local mean loss, n_local]
 
 
 def recording():
@@ -69,6 +71,11 @@ class MLPQuery(torch.autograd.Function):
         act = torch.empty((ops.act_bytes(n * S),), dtype=torch.uint8, device=rays.device)
         raw = ops.mlp_forward_train(model.packed(), rays, z, act)
         ctx.model, ctx.act = model, act
+        # how many times this network is queried under the tape (the coarse network also does the
+        # fine pass when network_fine is None)
+        if getattr(model, '_node_epoch', -1) != _TAPE_EPOCH:
+            model._node_epoch, model._nodes = _TAPE_EPOCH, 0
+        model._nodes += 1
         return raw
 
     @staticmethod
@@ -84,29 +91,39 @@ class MLPQuery(torch.autograd.Function):
         partial = model._grad_partial
         if partial is None or partial.device != dev or partial.numel() < ops.partial_bytes():
             partial = model._grad_partial = torch.empty((ops.partial_bytes(),), dtype=torch.uint8, device=dev)
-        # The network's whole gradient is ONE flat buffer (the 24 tensors are views): Adam reads it
-        # with one launch and data-parallel ranks exchange it with one collective.  The buffer is
-        # kept and reused from step to step; a network queried twice under one tape (coarse
-        # network doing the fine pass too) gets a fresh one the second time, autograd adds them.
-        first_use = getattr(model, '_grad_epoch', -1) != _TAPE_EPOCH
-        if first_use and getattr(model, '_grad_flat', None) is not None and model._grad_flat.device == dev:
+        # The network's whole gradient is ONE flat buffer (the 24 tensors are views, two more
+        # floats behind them carry the step's loss and ray count under data parallelism): Adam
+        # reads it with one launch and data-parallel ranks exchange it with one collective.  The
+        # buffer is kept and reused from step to step, so gradients returned by a tape are valid
+        # until the next tape's backward pass; a network queried twice under one tape (coarse
+        # network doing the fine pass too) gets fresh buffers, which autograd adds.
+        once = getattr(model, '_nodes', 1) == 1
+        n_par = model.flat.numel()
+        if once and getattr(model, '_grad_flat', None) is not None and model._grad_flat.device == dev:
             flat = model._grad_flat
         else:
-            flat = torch.empty_like(model.flat)
-            if first_use:
+            flat = torch.empty((n_par + _TAIL,), dtype=torch.float32, device=dev)
+            if once:
                 model._grad_flat = flat
         grads, at = [], 0
         for p in model.params:
             grads.append(flat[at:at + p.numel()].view(p.shape))
             at += p.numel()
-        ops.mlp_backward(model.packed_bwd(), ctx.act, d_raw, model.grad_scale, gbuf, partial, grads)
+        model.review_grad_status()
+        gscale = model.grad_scale if model.grad_scale is not None else -float(model.auto_target)
+        ops.mlp_backward(model.packed_bwd(), ctx.act, d_raw, gscale, gbuf, partial, grads)
+        model.post_grad_status()
         ctx.act = None
-        if first_use:
-            model._grad_epoch = _TAPE_EPOCH
-            # data parallel: start this network's all-reduce now, so that the fine network's
-            # exchange runs beside the coarse network's backward pass (autograd reaches the fine
-            # network first); train_step waits for the handles before the optimiser step
-            model._grad_work = parallel.allreduce_sum_(flat, async_op=True) if DP_OVERLAP else None
+        model._grad_work = None
+        if once and _DP_STEP is not None:
+            # data parallel: start this network's exchange now, so that the fine network's
+            # all-reduce runs beside the coarse network's backward pass (autograd reaches the fine
+            # network first); train_step waits for the handles before the optimiser step.  Only a
+            # train_step asks for this (a tape used on its own exchanges nothing), and only for a
+            # network with a single node under the tape: the gradients of a network queried twice
+            # are summed by autograd afterwards and exchanged once, by allreduce_gradients.
+            flat[n_par:].copy_(_DP_STEP.tail)
+            model._grad_work = parallel.allreduce_sum_(flat, async_op=True)
         return (None, None, None) + tuple(grads)
 
 
@@ -252,13 +269,9 @@ class Adam:
             for grp in self._groups:
                 gs = [grads[i] for i in grp['idx']]
                 # gradients that already tile one flat buffer are used in place
-                g0 = gs[0]
-                gbase = g0._base if g0._base is not None else g0
-                at, tiled = gbase.data_ptr(), gbase.numel() == grp['n']
-                for g in gs:
-                    tiled = tiled and g.data_ptr() == at and g.is_contiguous()
-                    at += g.numel() * 4
-                gflat = gbase.view(-1) if tiled else torch.cat([g.reshape(-1) for g in gs])
+                gflat = _tiled_flat(gs)
+                if gflat is None or gflat.numel() != grp['n']:
+                    gflat = torch.cat([g.reshape(-1) for g in gs])
                 if grp['theta'] is not None:
                     theta = grp['theta']
                 else:
@@ -278,11 +291,39 @@ class Adam:
         self.iterations += 1
 
 
+def _tiled_flat(tensors):
+    """The 1-d fp32 tensor that `tensors` tile back to back (views of one contiguous buffer, in
+    order, no gaps), or None.  The buffer may be longer than what they cover."""
+    t0 = tensors[0]
+    base = t0._base if t0._base is not None else t0
+    if base.dim() != 1 or not base.is_contiguous() or base.dtype != torch.float32:
+        return None
+    at = t0.data_ptr()
+    for t in tensors:
+        tb = t._base if t._base is not None else t
+        if tb is not base or t.data_ptr() != at or not t.is_contiguous():
+            return None
+        at += t.numel() * 4
+    off = (t0.data_ptr() - base.data_ptr()) // 4
+    n = (at - t0.data_ptr()) // 4
+    if off < 0 or off + n > base.numel():
+        return None
+    return base[off:off + n]
+
+
 # ---- data parallel ---------------------------------------------------------------------------
-# Ray-sharded data parallelism.  Every rank divides its loss by the GLOBAL ray count
-# (dp_loss_weight), so the SUM of the ranks' gradients is the gradient of the global mean loss
-# whatever the shard sizes; nothing is divided afterwards.
-DP_OVERLAP = True   # start a network's all-reduce inside its backward node (see MLPQuery.backward)
+# Ray-sharded data parallelism, two collectives per step (one per network) and nothing else: every
+# rank back-propagates n_local x its local MEAN loss, the flat gradient buffers are summed over the
+# ranks together with two trailing floats, [n_local x loss, n_local], and the sums are divided by
+# the summed ray count, which gives the gradient and the value of the GLOBAL mean loss whatever the
+# shard sizes.  (dp_loss_weight + allreduce_gradients(grads) remain for callers that weight the
+# loss themselves: one more small collective for the count.)
+class _DPStep:
+    def __init__(self, n_local, loss_local, device):
+        self.n_local = float(n_local)
+        # [n_local * local mean loss, n_local] on the device, written without a host round trip
+        self.tail = torch.stack([loss_local.detach().to(torch.float32) * self.n_local,
+                                 torch.full((), self.n_local, dtype=torch.float32, device=device)])
 
 
 def dp_loss_weight(n_local, device=None):
@@ -296,21 +337,25 @@ def dp_loss_weight(n_local, device=None):
     return (float(n_local) / n_global.clamp_min(1.)).to(torch.float32)
 
 
-def allreduce_gradients(grads):
+def allreduce_gradients(grads, step=None):
     """SUM over the ranks of a list of gradient tensors, with ONE collective per flat buffer they
     tile (a network's 24 gradients are views of one 2.38 MB buffer: no copy, no per-tensor call);
-    tensors that are not views of a common buffer are packed into one bucket first.  Exchanges
-    already started by the backward nodes (DP_OVERLAP) are only waited for.  Returns the list."""
+    tensors that do not tile a buffer of their own are packed into one bucket first.
+
+    step=None: a plain sum (the caller weighted its loss by dp_loss_weight); returns the list.
+    step=_DPStep (what train_step passes): the buffers were or are exchanged together with the
+    step's [n_local x loss, n_local] tail, exchanges already started by the backward nodes are only
+    waited for, every sum is divided by the summed ray count; returns (list, global mean loss)."""
     rank, world_size = parallel.world()
     if world_size == 1:
-        return grads
+        return grads if step is None else (grads, None)
     from .run_nerf_helpers import NerfModel
-    pending = [m for m in NerfModel.live() if getattr(m, '_grad_work', None) is not None]
-    done = set()
-    for m in pending:
-        m._grad_work.wait()
-        m._grad_work = None
-        done.add(m._grad_flat.data_ptr())
+    done = {}
+    for m in NerfModel.live():
+        if getattr(m, '_grad_work', None) is not None:
+            m._grad_work.wait()
+            m._grad_work = None
+            done[m._grad_flat.data_ptr()] = m._grad_flat
     groups, loose = {}, []
     for i, g in enumerate(grads):
         base = g._base if g._base is not None else g
@@ -319,20 +364,32 @@ def allreduce_gradients(grads):
         else:
             loose.append(i)
     out = list(grads)
+    tails = []   # summed [n x loss, n] of this step, one per exchange made with a tail
     for ptr, (base, idx) in groups.items():
-        covered = sum(grads[i].numel() for i in idx) == base.numel()
-        if not covered:
+        head = _tiled_flat([grads[i] for i in idx])
+        if ptr in done:
+            tails.append((base[-_TAIL:], base[:-_TAIL]))      # exchanged inside the backward node, tail included
+        elif step is None and head is not None:
+            parallel.allreduce_sum_(head)                     # in place, whatever lies behind the gradients
+        else:
             loose += idx
-        elif ptr not in done:
-            parallel.allreduce_sum_(base)
     if loose:
-        flat = torch.cat([grads[i].reshape(-1) for i in loose])
+        parts = [grads[i].reshape(-1) for i in loose] + ([step.tail] if step is not None else [])
+        flat = torch.cat(parts)
         parallel.allreduce_sum_(flat)
         at = 0
         for i in loose:
             out[i] = flat[at:at + grads[i].numel()].view(grads[i].shape)
             at += grads[i].numel()
-    return out
+        if step is not None:
+            tails.append((flat[at:], flat[:at]))
+    if step is None:
+        return out
+    with torch.no_grad():
+        for tail, head in tails:
+            head.div_(tail[1])
+    tail = tails[0][0]
+    return out, (tail[0] / tail[1])
 
 
 def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=()):
@@ -343,12 +400,9 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
     Under torch.distributed every rank passes ITS shard of the batch; the losses are weighted by
     n_local / n_global, the gradients summed over the ranks, and the returned loss is the global
     mean (psnr / psnr0 are those of the local shard)."""
+    global _DP_STEP
     from .run_nerf_helpers import img2mse, mse2psnr
     _, world_size = parallel.world()
-    weight = 1.0
-    if world_size > 1:
-        n_local = int(target_s.shape[0]) if hasattr(target_s, 'shape') else len(target_s)
-        weight = dp_loss_weight(n_local, batch_rays[0].device if isinstance(batch_rays[0], torch.Tensor) else None)
     with GradientTape() as tape:
         rgb, disp, acc, extras = render_fn(batch_rays)
         img_loss = img2mse(rgb, target_s)
@@ -359,13 +413,16 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
             img_loss0 = img2mse(extras['rgb0'], target_s)
             loss = loss + img_loss0
             psnr0 = mse2psnr(img_loss0.detach())
-        if world_size > 1:
-            loss = loss * weight
-    gradients = tape.gradient(loss, grad_vars)
-    gradients = allreduce_gradients(gradients)
+    if world_size == 1:
+        gradients = tape.gradient(loss, grad_vars)
+    else:
+        n_local = int(target_s.shape[0]) if hasattr(target_s, 'shape') else len(target_s)
+        step = _DPStep(n_local, loss, loss.device)
+        _DP_STEP = step
+        try:
+            gradients = tape.gradient(loss * step.n_local, grad_vars)
+        finally:
+            _DP_STEP = None
+        gradients, loss = allreduce_gradients(gradients, step)
     optimizer.apply_gradients(zip(gradients, grad_vars))
-    loss = loss.detach()
-    if world_size > 1:
-        loss = loss.clone()
-        parallel.allreduce_sum_(loss)
-    return loss, psnr, psnr0
+    return loss.detach(), psnr, psnr0

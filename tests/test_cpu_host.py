@@ -176,6 +176,17 @@ def _worker(rank, world_size, port, tmp):
         # tensors that do not tile one buffer are packed into one bucket
         out2 = training.allreduce_gradients([gw.clone(), gb.clone()])
         assert torch.allclose(out2[0], fw, atol=1e-6) and torch.allclose(out2[1], fb, atol=1e-6)
+        # what train_step does: every rank back-propagates n_local x its local mean loss, the
+        # gradients travel with [n_local x loss, n_local] behind them in ONE bucket, and the sums are
+        # divided by the summed count -> gradient and value of the global mean loss, no other collective
+        w3 = torch.nn.Parameter(torch.ones(11, 3))
+        b3 = torch.nn.Parameter(torch.zeros(3))
+        local = ((mine @ w3 + b3 - target[lo:hi]) ** 2).mean()
+        step = training._DPStep(hi - lo, local, torch.device('cpu'))
+        g3 = torch.autograd.grad(local * step.n_local, [w3, b3])
+        out3, loss3 = training.allreduce_gradients(list(g3), step)
+        assert torch.allclose(out3[0], fw, atol=1e-6) and torch.allclose(out3[1], fb, atol=1e-6)
+        assert abs(float(loss3) - float(loss_full)) < 1e-6 * float(loss_full), (float(loss3), float(loss_full))
         # the averaged loss a step reports, and identical replicas after a broadcast
 
         class Net:

@@ -487,3 +487,54 @@ def test_trains_an_analytic_scene_end_to_end(gpu):
         loss, psnr, psnr0 = training.train_step(fn, rays, target, grad_vars, opt)
     end = held_out_psnr()
     assert start < 12. and end > 22. and float(psnr) > 25., (start, end, float(psnr))
+
+
+def _sharded_render_worker(rank, world_size, port, tmp):
+    """One of two ranks sharing the one GPU of the box (gloo; over RCCL on a multi-GPU node)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from nerf_amd import parallel
+    from nerf_amd.run_nerf import create_nerf, render, render_path
+    torch.cuda.set_device(0)
+    gpu = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
+    try:
+        torch.manual_seed(50 + rank)               # create_nerf broadcasts rank 0's weights
+        kw_train, kw_test, start, _, models = create_nerf(default_args())
+        assert start == 0
+        rb = synthetic_rays(1001, seed=9)          # odd: shards of 501 and 500 rays, several chunks each
+        rays = (torch.as_tensor(rb[:, :3]).to(gpu), torch.as_tensor(rb[:, 3:6]).to(gpu))
+        one = render(1, 1, 1., chunk=128, rays=rays, near=2., far=6., **kw_test)
+        both = parallel.render(1, 1, 1., chunk=128, rays=rays, near=2., far=6., **kw_test)
+        for a, b in zip(one[:3], both[:3]):
+            assert a.shape == b.shape and torch.equal(a, b)
+        assert set(one[3]) == set(both[3])
+        for k in one[3]:
+            assert torch.equal(one[3][k], both[3][k]), k
+        # a camera view through render_path, sharded by a key in its render_kwargs
+        H = W = 9
+        poses = [pose_spherical(30., -30., 4.)]
+        r1, e1 = render_path(poses, (H, W, 12.), 64, dict(kw_test, near=2., far=6.))
+        r2, e2 = render_path(poses, (H, W, 12.), 64, dict(kw_test, near=2., far=6., shard_over_ranks=True))
+        assert r1.shape == (1, H, W, 3) and np.array_equal(r1, r2) and np.array_equal(e1['disp'], e2['disp'])
+        # the step a run resumes from is rank 0's on every rank
+        assert parallel.broadcast_int(7 + rank) == 7
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_render_equals_single_rank_render_two_ranks(gpu, tmp_path):
+    """parallel.render / render(shard_over_ranks=True) on two ranks: every rank gets, bit for bit,
+    what one process renders alone (run_nerf.py:28-161 with the ray batch split over the ranks)."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_render_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")

@@ -488,12 +488,11 @@ def _dp_worker(rank, world_size, port, tmp):
                                     perturb_u=_t(pu[sl], gpu), pdf_u=_t(uu[sl], gpu), **kw_train)
         # reference: the whole batch on this rank alone, no exchange
         from nerf_amd.run_nerf_helpers import img2mse
-        training.DP_OVERLAP = False
+        # (a tape on its own exchanges nothing: only train_step starts collectives)
         with training.GradientTape() as tape:
             rgb, _, _, ex = fn_for(slice(0, n))((_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)))
             full_loss = img2mse(rgb, _t(target, gpu)) + img2mse(ex['rgb0'], _t(target, gpu))
         full = [g.clone() for g in tape.gradient(full_loss, grad_vars)]
-        training.DP_OVERLAP = True
         # the data-parallel step on this rank's shard
         seen = {}
 
@@ -517,9 +516,79 @@ def _dp_worker(rank, world_size, port, tmp):
             assert not torch.equal(m.flat, s0)
             dist.all_gather(both, m.flat.detach())
             assert torch.equal(both[0], both[1]), "replicas diverged"
+        # a network queried twice under one tape (network_fine=None with N_importance > 0: the
+        # coarse network also does the fine pass, run_nerf.py:216-227): its two gradient
+        # contributions are summed by autograd and exchanged ONCE
+        kw_one = dict(kw_train, network_fine=None)
+
+        def fn_one(sl):
+            return lambda r: render(1, 1, 1., chunk=1024, rays=r, near=2., far=6., retraw=True,
+                                    perturb_u=_t(pu[sl], gpu), pdf_u=_t(uu[sl], gpu), **kw_one)
+        cvars = grad_vars[:24]
+        with training.GradientTape() as tape:
+            rgb, _, _, ex = fn_one(slice(0, n))((_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)))
+            full_loss = img2mse(rgb, _t(target, gpu)) + img2mse(ex['rgb0'], _t(target, gpu))
+        full = [g.clone() for g in tape.gradient(full_loss, cvars)]
+        seen.clear()
+        loss, _, _ = training.train_step(fn_one(sl), (_t(rb[sl, :3], gpu), _t(rb[sl, 3:6], gpu)),
+                                         _t(target[sl], gpu), cvars, Probe(training.ExponentialDecay(5e-4, 250 * 1000, 0.1)))
+        np.testing.assert_allclose(float(loss), float(full_loss), rtol=1e-4)
+        a = torch.cat([g.reshape(-1) for g in seen['grads']]).double()
+        b = torch.cat([g.reshape(-1) for g in full]).double()
+        assert float((a - b).norm() / b.norm()) < 2e-3
+        dist.all_gather(both, nets[0].flat.detach())
+        assert torch.equal(both[0], both[1]), "replicas diverged (network queried twice)"
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
+
+
+def test_saturated_step_is_skipped_and_the_scale_backs_off(gpu):
+    """Kernels scaled 3x amplify the gradient by more than the default automatic scale leaves
+    room for (test_mlp_backward): the saturated passes yield NaN gradients, which the Adam kernel
+    skips (weights and moments untouched); the target of the automatic scale is lowered from the
+    status of earlier passes and the following steps use sound gradients.  No step ever writes a
+    non-finite weight.  An explicit target (gscale < 0) does the same in one call."""
+    from nerf_amd import ops, training
+    from nerf_amd.run_nerf_helpers import init_nerf_model
+    rng = np.random.default_rng(108)
+    ws = trained_like_weights(rng, scale_hidden=3.)
+    m = init_nerf_model(8, 256, 63, 27, 4, [4], True, device=gpu)
+    m.set_weights(ws)
+    n, S = 8, 64
+    rays = _t(synthetic_rays(n, seed=8), gpu)
+    z = ops.sample_z(rays, S)
+    d_raw = _t((rng.normal(size=(n, S, 4)) * 1e-4).astype(np.float32), gpu)
+    opt = training.Adam(1e-5)
+    start = m.flat.detach().clone()
+    flags, targets = [], []
+    for it in range(10):
+        with training.GradientTape() as tape:
+            raw = training.MLPQuery.apply(rays, z, m, *m.params)
+            loss = (raw * d_raw).sum()
+        grads = tape.gradient(loss, m.params)
+        before = m.flat.detach().clone()
+        opt.apply_gradients(zip(grads, m.params))
+        f = m.grad_status()[0]
+        flags.append(f)
+        targets.append(m.auto_target)
+        assert bool(torch.isfinite(m.flat).all()), it
+        if f & ops.GRAD_SATURATED:   # NaN gradients: the step was skipped as a whole
+            assert all(bool(torch.isnan(g).all()) for g in grads) and torch.equal(m.flat, before), it
+    assert flags[0] & ops.GRAD_SATURATED and flags[1] & ops.GRAD_SATURATED, flags   # the default target is too high here ...
+    assert flags[-1] == 0 and targets[-1] < 256., (flags, targets)                  # ... and has come down by itself
+    assert not torch.equal(m.flat, start)
+    # the same in one call
+    act = torch.zeros((ops.act_bytes(n * S),), dtype=torch.uint8, device=gpu)
+    ops.mlp_forward_train(m.packed(), rays, z, act)
+    gbuf = torch.empty((ops.grad_bytes(n * S),), dtype=torch.uint8, device=gpu)
+    part = torch.empty((ops.partial_bytes(),), dtype=torch.uint8, device=gpu)
+    g = [torch.zeros_like(p) for p in m.params]
+    ops.mlp_backward(m.packed_bwd(), act, d_raw, -4.0, gbuf, part, g)
+    fl, gs, mx = ops.mlp_backward_status(part)
+    assert fl == 0 and 4. <= gs * mx < 8. and all(bool(torch.isfinite(x).all()) for x in g)
+    with pytest.raises(Exception):
+        ops.mlp_backward(m.packed_bwd(), act, d_raw, -3.0, gbuf, part, g)   # not a power of two
 
 
 def test_data_parallel_train_step_two_ranks(gpu, tmp_path):

@@ -91,10 +91,8 @@ def _write_png16(path, img, filters):
 
 
 @pytest.mark.parametrize("filters", [[0], [0, 1, 2, 3, 4]])
-def test_png_reader_16_bit_depth_maps(tmp_path, filters):
-    """load_blender.py:112-121 reads Kinect depth maps as 16-bit PNGs whose invalid readings are
-    0 and 65535; smooth_kinect_depth fills them with the nearest valid one."""
-    from nerf_amd.load_blender import smooth_kinect_depth
+def test_png_reader_16_bit_grey(tmp_path, filters):
+    """16-bit grey PNGs come back as uint16 arrays, whatever the row filters."""
     rng = np.random.default_rng(5)
     depth = rng.integers(400, 3000, size=(9, 11)).astype(np.uint16)
     depth[2, 3], depth[7, 1] = 0, 65535
@@ -103,9 +101,6 @@ def test_png_reader_16_bit_depth_maps(tmp_path, filters):
     got = imageio_lite.imread(p)
     assert got.dtype == np.uint16
     np.testing.assert_array_equal(got, depth)
-    smooth = smooth_kinect_depth(got)
-    assert smooth.dtype == np.float32 and smooth.min() >= 0.4 and smooth.max() < 3.0
-    np.testing.assert_allclose(smooth[0, 0], depth[0, 0] / 1000., rtol=1e-6)
 
 
 # ---- option reader ------------------------------------------------------------------------------

@@ -113,3 +113,25 @@ def test_single_image_batches_respect_precrop(gpu):
     k = int(np.argmax([h.any(1).all() for h in hits]))
     pix = hits[k].argmax(1)
     assert len(set(pix.tolist())) == 40 and set(pix.tolist()) <= set(win.tolist())
+
+
+@pytest.mark.gpu
+def test_data_parallel_batchers_split_one_global_batch(gpu):
+    """RayBatcher(rank, world_size): the ranks draw the same global batch from a common seed and
+    keep disjoint contiguous slices of it, in both modes (run_nerf.py:695-766 run by R processes)."""
+    from nerf_amd.ray_batches import RayBatcher
+    H, W, focal, poses, images = _scene()
+    i_train = [0, 1, 3]
+    N_rand, R = 101, 3                             # slices of 34, 34 and 33 rays
+    for batching in (True, False):
+        whole = RayBatcher(H, W, focal, poses, images, i_train, N_rand, use_batching=batching, device=gpu, seed=11)
+        parts = [RayBatcher(H, W, focal, poses, images, i_train, N_rand, use_batching=batching, device=gpu, seed=11,
+                            rank=r, world_size=R) for r in range(R)]
+        for step in range(3):
+            rays, tgt = whole.sample(step)
+            got = [p.sample(step) for p in parts]
+            assert [g[0].shape[1] for g in got] == [34, 34, 33]
+            assert torch.equal(torch.cat([g[0] for g in got], 1), rays)
+            assert torch.equal(torch.cat([g[1] for g in got], 0), tgt)
+    with pytest.raises(ValueError):
+        RayBatcher(H, W, focal, poses, images, i_train, N_rand, device=gpu, rank=0, world_size=2)   # no common seed

@@ -36,30 +36,45 @@ def test_render_rays_static_matches_workspace_form(gpu):
         new = lambda *s: torch.full(s, float('inf'), dtype=torch.float32, device=gpu)
         return [new(n, 3), new(n), new(n), new(n), new(n, 3), new(n), new(n), new(n)]
 
-    def run(n, seed, static, with_u):
+    def prepare(n, seed, with_u):
         rays = _t(synthetic_rays(n, seed=seed), gpu)
         r = np.random.default_rng(seed)
         pu = _t(r.uniform(size=(n, Sc)), gpu) if with_u else None
         uu = _t(r.uniform(size=(n, Si)), gpu) if with_u else None
         out = outputs(n)
-        args = [nv.ptr(pc), nv.ptr(pf), nv.ptr(rays), 11, n, Sc, Si, 0, 1, nv.ptr(pu), nv.ptr(uu)] + [nv.ptr(o) for o in out]
+        keep = (rays, pu, uu)   # alive until the call has finished
+        return out, keep, [nv.ptr(pc), nv.ptr(pf), nv.ptr(rays), 11, n, Sc, Si, 0, 1, nv.ptr(pu), nv.ptr(uu)] + [nv.ptr(o) for o in out]
+
+    def run(n, seed, static, with_u):
+        out, keep, args = prepare(n, seed, with_u)
         if static:
-            nv.check(lib.nerf_render_rays_static(*args, nv.stream()), "nerf_render_rays_static")
+            # inputs and outputs exist, the stream is idle: whatever the device's free memory
+            # does between here and the end of the call is the entry point's own doing
+            stream = nv.stream()
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info()[0]
+            nv.check(lib.nerf_render_rays_static(*args, stream), "nerf_render_rays_static")
+            torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info()[0] == free_before, "nerf_render_rays_static allocated device memory"
         else:
             need = int(lib.nerf_render_rays_workspace_bytes(n, Sc, Si))
             ws = torch.empty((need,), dtype=torch.uint8, device=gpu)
             nv.check(lib.nerf_render_rays(*args, nv.ptr(ws), nv.stream()), "nerf_render_rays")
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         return out
 
-    # two calls in a row through the built-in array, the second on a smaller batch (the array
-    # still holds the first call's intermediates), each against the workspace form
+    # two calls in a row through the built-in array (each bracketed by the device's free-memory
+    # figure, the first one included), the second on a smaller batch (the array still holds the
+    # first call's intermediates), each against the workspace form
     n_big = 9000
     assert int(lib.nerf_render_rays_workspace_bytes(n_big, Sc, Si)) <= cap
+    # set-up (n_rays = 0): the runtime loads the code object that holds the array on this GPU
+    out0, keep0, args0 = prepare(1, 0, False)
+    args0[4] = 0
+    nv.check(lib.nerf_render_rays_static(*args0, nv.stream()), "nerf_render_rays_static(set-up)")
+    assert bool(torch.isinf(out0[0]).all())            # nothing was rendered
     first = run(n_big, 1, True, False)
-    free_before = torch.cuda.mem_get_info()[0]
     second = run(2500, 2, True, True)
-    assert torch.cuda.mem_get_info()[0] == free_before          # nothing was allocated on the device
     for got, want in ((first, run(n_big, 1, False, False)), (second, run(2500, 2, False, True))):
         for g, w in zip(got, want):
             assert bool(torch.isfinite(torch.nan_to_num(g, nan=0.)).all())   # every output was written
