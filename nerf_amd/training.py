@@ -301,7 +301,7 @@ def _tiled_flat(tensors):
     at = t0.data_ptr()
     for t in tensors:
         tb = t._base if t._base is not None else t
-        if tb is not base or t.data_ptr() != at or not t.is_contiguous():
+        if tb.data_ptr() != base.data_ptr() or tb.numel() != base.numel() or t.data_ptr() != at or not t.is_contiguous():
             return None
         at += t.numel() * 4
     off = (t0.data_ptr() - base.data_ptr()) // 4
@@ -397,9 +397,10 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
     photometric configuration): returns (loss, psnr, psnr0) as 0-d tensors.
     render_fn(rays) must call render(..., rays=rays, **render_kwargs_train).
 
-    Under torch.distributed every rank passes ITS shard of the batch; the losses are weighted by
-    n_local / n_global, the gradients summed over the ranks, and the returned loss is the global
-    mean (psnr / psnr0 are those of the local shard)."""
+    Under torch.distributed every rank passes ITS (non-empty) shard of the batch: the rank
+    back-propagates n_local x its local mean loss, each network's gradient buffer is summed over
+    the ranks with [n_local x loss, n_local] behind it and divided by the summed ray count, and
+    the returned loss is the global mean (psnr / psnr0 are those of the local shard)."""
     global _DP_STEP
     from .run_nerf_helpers import img2mse, mse2psnr
     _, world_size = parallel.world()
