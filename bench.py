@@ -347,7 +347,7 @@ def main():
         if not (a.chunk == 131072 and a.rays % a.chunk == 0):
             traffic, traffic_note = None, "counter summary is for 131072-ray chunks"
         cpu = None
-        if a.cpu_rays > 0:
+        if a.cpu_rays > 0 and world == 1:   # the CPU leg belongs to the one-GPU line only
             v, secs = cpu_baseline(a.cpu_rays)
             cpu = {"value": round(v, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
                    "sample": f"{min(a.cpu_rays, 160000)} consecutive rays (one chunk of five) from the middle of the 400x400 "
