@@ -148,6 +148,13 @@ def _worker(rank, world_size, port, tmp):
         for k in full:
             assert out[k].shape == full[k].shape, k
             assert torch.equal(out[k], full[k]), k
+        # every per-ray output of a shard in ONE collective, whatever its trailing shape; the resume step of rank 0
+        lo_r, hi_r = parallel.shard_bounds(n, rank, world_size)
+        part = {'rgb_map': rays[lo_r:hi_r, 0:3], 'raw': rays[lo_r:hi_r, :8].reshape(-1, 2, 4), 'z_std': rays[lo_r:hi_r, 9]}
+        whole = parallel.gather_dict(part, n)
+        assert torch.equal(whole['rgb_map'], rays[:, 0:3]) and torch.equal(whole['z_std'], rays[:, 9])
+        assert whole['raw'].shape == (n, 2, 4) and torch.equal(whole['raw'], rays[:, :8].reshape(-1, 2, 4))
+        assert parallel.broadcast_int(40 + rank) == 40
         # data-parallel gradient, the product's own functions on CPU tensors: unequal shards (501 /
         # 500 rays), each rank's MEAN loss weighted by n_local / n_global, SUM all-reduce of the flat
         # gradient buffer in place -> the gradient of the global mean
