@@ -262,6 +262,17 @@ int nerf_mlp_backward_status(const void* partial, int* flags, float* gscale_used
 int nerf_mse_loss_fwd_bwd(const float* x, const float* y, int64_t count, float inv_count,
                           float upstream, float* loss, float* d_x, nerf_stream_t stream);
 
+/* The loss of the plain photometric configuration and everything the step derives from it, in
+ * one launch (run_nerf.py:781 img_loss, :797 psnr, :809-811 img_loss0, psnr0, loss += img_loss0;
+ * run_nerf_helpers.py:11-12 img2mse, mse2psnr).  rgb, rgb0 (NULL when there is no coarse map) and
+ * target hold `count` scalars each.  out[0..4] = loss (img_loss + img_loss0), img_loss, img_loss0,
+ * psnr, psnr0 (overwritten, nothing to zero; out[2] = out[4] = 0 without rgb0);
+ * d_rgb = grad_weight * d loss / d rgb, d_rgb0 likewise (either may be NULL).  grad_weight is 1 for
+ * a single process; a data-parallel rank passes its ray count (see the gradient exchange of
+ * nerf_mlp_backward's callers: gradients are summed over the ranks and divided by the summed count). */
+int nerf_photometric_loss(const float* rgb, const float* rgb0, const float* target, int64_t count,
+                          float grad_weight, float* out, float* d_rgb, float* d_rgb0, nerf_stream_t stream);
+
 /* tf.keras.optimizers.Adam dense update (run_nerf.py:605,:826) over a flat buffer of n scalars:
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr_t m/(sqrt(v)+eps), where the caller
  * passes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (eps is not bias-corrected, as in Keras).  Elements whose

@@ -48,6 +48,7 @@ SIGNATURES = {
     "nerf_mlp_backward": (_I, [_P, _P, _P, _L, _F, _P, _P, _P, _I, _P]),
     "nerf_mlp_backward_status": (_I, [_P, _P, _P, _P, _P]),
     "nerf_mse_loss_fwd_bwd": (_I, [_P, _P, _L, _F, _F, _P, _P, _P]),
+    "nerf_photometric_loss": (_I, [_P, _P, _P, _L, _F, _P, _P, _P, _P]),
     "nerf_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P]),
 }
 

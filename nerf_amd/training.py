@@ -55,8 +55,30 @@ class GradientTape:
 
     def gradient(self, loss, variables):
         variables = list(variables)
-        grads = torch.autograd.grad(loss, variables, allow_unused=True)
+        grads = torch.autograd.grad(loss, variables, grad_outputs=_unit_seed(loss), allow_unused=True)
         return [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, variables)]
+
+
+# The gradient a tape starts the backward pass with is a constant 1: one cached 0-d tensor per
+# device (instead of a fill per step), which the loss nodes below recognise by its address, so
+# that they hand out the gradient their forward kernel already wrote instead of launching a
+# multiplication by one.  Any other incoming gradient (a weighted loss, a sum of paths) is
+# multiplied in as usual.
+_UNIT_SEEDS = {}
+
+
+def _unit_seed(loss):
+    if not (isinstance(loss, torch.Tensor) and loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32):
+        return None
+    seed = _UNIT_SEEDS.get(loss.device)
+    if seed is None:
+        seed = _UNIT_SEEDS[loss.device] = torch.ones((), dtype=torch.float32, device=loss.device)
+    return seed
+
+
+def _is_unit_seed(g):
+    seed = _UNIT_SEEDS.get(g.device)
+    return seed is not None and g.dim() == 0 and g.data_ptr() == seed.data_ptr()
 
 
 # ---- autograd nodes over the kernels --------------------------------------------------------
@@ -181,12 +203,64 @@ class _MSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d_x,) = ctx.saved_tensors
-        return (None if g is None else d_x * g), None
+        if g is None:
+            return None, None
+        return (d_x if _is_unit_seed(g) else d_x * g), None
 
 
 def mse(x, y):
     """img2mse (run_nerf_helpers.py:11) with the gradient produced in the same kernel pass."""
     return _MSE.apply(nv.f32(x), y)
+
+
+class _Photometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, rgb0, target, grad_weight):
+        ctx.set_materialize_grads(False)
+        rgb = rgb.contiguous()
+        target = nv.f32(target, rgb.device)
+        if rgb.shape != target.shape or (rgb0 is not None and rgb0.shape != target.shape):
+            raise ValueError(f"photometric_loss: shapes {tuple(rgb.shape)}, "
+                             f"{None if rgb0 is None else tuple(rgb0.shape)} and {tuple(target.shape)} differ")
+        if rgb.numel() == 0:
+            raise ValueError("photometric_loss: empty batch")
+        rgb0 = None if rgb0 is None else rgb0.contiguous()
+        out = torch.empty((8,), dtype=torch.float32, device=rgb.device)
+        d_rgb = torch.empty_like(rgb)
+        d_rgb0 = None if rgb0 is None else torch.empty_like(rgb0)
+        with torch.cuda.device(rgb.device):
+            nv.check(nv.lib().nerf_photometric_loss(nv.ptr(rgb), nv.ptr(rgb0), nv.ptr(target), rgb.numel(),
+                                                    float(grad_weight), nv.ptr(out), nv.ptr(d_rgb), nv.ptr(d_rgb0),
+                                                    nv.stream()), "nerf_photometric_loss")
+        ctx.save_for_backward(d_rgb, d_rgb0)
+        loss, stats = out[0], out[1:5]
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        d_rgb, d_rgb0 = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None
+        if not _is_unit_seed(g):
+            d_rgb = d_rgb * g
+            d_rgb0 = None if d_rgb0 is None else d_rgb0 * g
+        return d_rgb, d_rgb0, None, None
+
+
+def photometric_loss(rgb, rgb0, target, grad_weight=1.0):
+    """The loss of the plain photometric configuration with everything the step reports, one kernel
+    launch (run_nerf.py:781, :797, :809-811): returns (loss, img_loss, img_loss0, psnr, psnr0) as
+    0-d tensors, loss = img2mse(rgb, target) + img2mse(rgb0, target) being the differentiable one
+    (rgb0 None: no coarse term; img_loss0 and psnr0 are then None).  The gradient that flows back
+    from `loss` is grad_weight times the true one (data-parallel ranks pass their ray count, see
+    train_step)."""
+    rgb = nv.f32(rgb)
+    rgb0 = None if rgb0 is None else nv.f32(rgb0, rgb.device)
+    loss, stats = _Photometric.apply(rgb, rgb0, target, grad_weight)
+    if rgb0 is None:
+        return loss, stats[0], None, stats[2], None
+    return loss, stats[0], stats[1], stats[2], stats[3]
 
 
 # ---- optimiser (run_nerf.py:601-605, :826) ----------------------------------------------------
@@ -402,26 +476,22 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
     the ranks with [n_local x loss, n_local] behind it and divided by the summed ray count, and
     the returned loss is the global mean (psnr / psnr0 are those of the local shard)."""
     global _DP_STEP
-    from .run_nerf_helpers import img2mse, mse2psnr
     _, world_size = parallel.world()
+    n_local = int(target_s.shape[0]) if hasattr(target_s, 'shape') else len(target_s)
     with GradientTape() as tape:
         rgb, disp, acc, extras = render_fn(batch_rays)
-        img_loss = img2mse(rgb, target_s)
-        loss = img_loss
-        psnr = mse2psnr(img_loss.detach())
-        psnr0 = None
-        if 'rgb0' in extras:
-            img_loss0 = img2mse(extras['rgb0'], target_s)
-            loss = loss + img_loss0
-            psnr0 = mse2psnr(img_loss0.detach())
+        # img_loss, psnr, img_loss0, psnr0 and loss = img_loss + img_loss0 in one launch; a
+        # data-parallel rank's gradient carries its ray count (the sums over the ranks are divided
+        # by the summed count)
+        loss, _, _, psnr, psnr0 = photometric_loss(rgb, extras.get('rgb0'), target_s,
+                                                   grad_weight=1.0 if world_size == 1 else float(n_local))
     if world_size == 1:
         gradients = tape.gradient(loss, grad_vars)
     else:
-        n_local = int(target_s.shape[0]) if hasattr(target_s, 'shape') else len(target_s)
         step = _DPStep(n_local, loss, loss.device)
         _DP_STEP = step
         try:
-            gradients = tape.gradient(loss * step.n_local, grad_vars)
+            gradients = tape.gradient(loss, grad_vars)
         finally:
             _DP_STEP = None
         gradients, loss = allreduce_gradients(gradients, step)

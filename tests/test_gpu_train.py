@@ -284,6 +284,51 @@ def test_mse_and_keras_adam(gpu):
         assert len(back) == 3 and int(back[0]) == 5
 
 
+@pytest.mark.parametrize("n,coarse", [(1, True), (37, False), (4096, True), (100003, True)])
+def test_photometric_loss_in_one_launch(gpu, n, coarse):
+    """training.photometric_loss (what train_step uses) against the oracle's img2mse / mse2psnr and
+    against img2mse + img2mse through the tape: loss, both terms, both PSNRs, both gradients; with
+    the tape's unit seed (no multiplication launched), with a weighted loss, and with grad_weight."""
+    from nerf_amd import training
+    from nerf_amd.run_nerf_helpers import img2mse
+    from oracle import nerf_oracle as orc
+    rng = np.random.default_rng(n)
+    x, x0, y = (rng.uniform(size=(n, 3)).astype(np.float32) for _ in range(3))
+    f64 = lambda a: a.astype(np.float64)
+    want, want0 = orc.img2mse(f64(x), f64(y)), orc.img2mse(f64(x0), f64(y))
+    for weight, outer in [(1.0, None), (1.0, 3.0), (5.0, None)]:
+        xt, x0t = _t(x, gpu).requires_grad_(True), _t(x0, gpu).requires_grad_(True)
+        with training.GradientTape() as tape:
+            loss, img_loss, img_loss0, psnr, psnr0 = training.photometric_loss(xt, x0t if coarse else None, _t(y, gpu),
+                                                                             grad_weight=weight)
+            top = loss if outer is None else loss * outer
+        gx, gx0 = tape.gradient(top, [xt, x0t])
+        np.testing.assert_allclose(float(img_loss), want, rtol=1e-5)
+        np.testing.assert_allclose(float(psnr), orc.mse2psnr(want), rtol=1e-5, atol=1e-5)
+        scale = weight * (outer or 1.0)
+        np.testing.assert_allclose(gx.cpu().numpy(), scale * 2 * (f64(x) - y) / x.size, rtol=2e-6, atol=1e-12)
+        if coarse:
+            np.testing.assert_allclose(float(loss), want + want0, rtol=1e-5)
+            np.testing.assert_allclose(float(img_loss0), want0, rtol=1e-5)
+            np.testing.assert_allclose(float(psnr0), orc.mse2psnr(want0), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(gx0.cpu().numpy(), scale * 2 * (f64(x0) - y) / x.size, rtol=2e-6, atol=1e-12)
+        else:
+            np.testing.assert_allclose(float(loss), want, rtol=1e-5)
+            assert img_loss0 is None and psnr0 is None and not bool(gx0.any())
+    # the two-node form a caller's own loop would write gives the same numbers
+    xt, x0t = _t(x, gpu).requires_grad_(True), _t(x0, gpu).requires_grad_(True)
+    with training.GradientTape() as tape:
+        loss2 = img2mse(xt, _t(y, gpu)) + img2mse(x0t, _t(y, gpu))
+    hx, hx0 = tape.gradient(loss2, [xt, x0t])
+    np.testing.assert_allclose(float(loss2), want + want0, rtol=1e-5)
+    np.testing.assert_allclose(hx.cpu().numpy(), 2 * (f64(x) - y) / x.size, rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose(hx0.cpu().numpy(), 2 * (f64(x0) - y) / x.size, rtol=2e-6, atol=1e-12)
+    # same inputs, same bits (one workgroup, no atomics)
+    a = training.photometric_loss(_t(x, gpu), _t(x0, gpu), _t(y, gpu))[0]
+    b = training.photometric_loss(_t(x, gpu), _t(x0, gpu), _t(y, gpu))[0]
+    assert float(a) == float(b)
+
+
 @pytest.mark.parametrize("n", [96, 4096])
 def test_training_step_gradients_end_to_end(gpu, n):
     """tape.gradient over render() (64+128 samples, perturb and random resampling uniforms shared
