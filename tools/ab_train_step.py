@@ -1,8 +1,11 @@
 """Same-process A/B of one optimisation step (4096 rays, 64+128 samples, perturb=1, as bench.py's
 training leg): training.train_step against the same step written the long way (img2mse twice,
 mse2psnr twice, a sum, the tape seeded by autograd), in alternating blocks so that the box, its
-clock and its temperature are the same for both.  Prints the median block time of each.
-    python tools/ab_train_step.py [blocks] [steps per block]"""
+clock and its temperature are the same for both.  Prints the median block time of each.  Names
+given after the two counts are environment switches of experimental library builds: train_step
+is timed once more with each of them set.
+    python tools/ab_train_step.py [blocks] [steps per block] [ENV_SWITCH ...]"""
+import os
 import statistics
 import sys
 import time
@@ -45,17 +48,28 @@ def main():
         opt.apply_gradients(zip(grads, grad_vars))
         return loss.detach(), psnr, psnr0
 
-    times = {"train_step": [], "long way": []}
-    for name, f in (("train_step", fused), ("long way", long_way)):
-        for _ in range(5):
-            f()
-    torch.cuda.synchronize()
-    for _ in range(blocks):
-        for name, f in (("train_step", fused), ("long way", long_way)):
-            t0 = time.perf_counter()
-            for _ in range(steps):
+    variants = [("train_step", fused, None), ("long way", long_way, None)]
+    variants += [("train_step " + env, fused, env) for env in sys.argv[3:]]
+    times = {name: [] for name, _, _ in variants}
+
+    def run(f, env, count):
+        if env:
+            os.environ[env] = "1"
+        try:
+            for _ in range(count):
                 out = f()
             torch.cuda.synchronize()
+        finally:
+            if env:
+                del os.environ[env]
+        return out
+
+    for name, f, env in variants:
+        run(f, env, 5)
+    for _ in range(blocks):
+        for name, f, env in variants:
+            t0 = time.perf_counter()
+            out = run(f, env, steps)
             times[name].append((time.perf_counter() - t0) / steps * 1e3)
     for name, ts in times.items():
         print(f"{name:12s} median {statistics.median(ts):.3f} ms/step   blocks: " + " ".join(f"{t:.3f}" for t in ts))
