@@ -55,30 +55,8 @@ class GradientTape:
 
     def gradient(self, loss, variables):
         variables = list(variables)
-        grads = torch.autograd.grad(loss, variables, grad_outputs=_unit_seed(loss), allow_unused=True)
+        grads = torch.autograd.grad(loss, variables, allow_unused=True)
         return [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, variables)]
-
-
-# The gradient a tape starts the backward pass with is a constant 1: one cached 0-d tensor per
-# device (instead of a fill per step), which the loss nodes below recognise by its address, so
-# that they hand out the gradient their forward kernel already wrote instead of launching a
-# multiplication by one.  Any other incoming gradient (a weighted loss, a sum of paths) is
-# multiplied in as usual.
-_UNIT_SEEDS = {}
-
-
-def _unit_seed(loss):
-    if not (isinstance(loss, torch.Tensor) and loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32):
-        return None
-    seed = _UNIT_SEEDS.get(loss.device)
-    if seed is None:
-        seed = _UNIT_SEEDS[loss.device] = torch.ones((), dtype=torch.float32, device=loss.device)
-    return seed
-
-
-def _is_unit_seed(g):
-    seed = _UNIT_SEEDS.get(g.device)
-    return seed is not None and g.dim() == 0 and g.data_ptr() == seed.data_ptr()
 
 
 # ---- autograd nodes over the kernels --------------------------------------------------------
@@ -203,9 +181,7 @@ class _MSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d_x,) = ctx.saved_tensors
-        if g is None:
-            return None, None
-        return (d_x if _is_unit_seed(g) else d_x * g), None
+        return (None if g is None else d_x * g), None
 
 
 def mse(x, y):
@@ -242,10 +218,7 @@ class _Photometric(torch.autograd.Function):
         d_rgb, d_rgb0 = ctx.saved_tensors
         if g is None:
             return None, None, None, None
-        if not _is_unit_seed(g):
-            d_rgb = d_rgb * g
-            d_rgb0 = None if d_rgb0 is None else d_rgb0 * g
-        return d_rgb, d_rgb0, None, None
+        return d_rgb * g, (None if d_rgb0 is None else d_rgb0 * g), None, None
 
 
 def photometric_loss(rgb, rgb0, target, grad_weight=1.0):

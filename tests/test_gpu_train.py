@@ -287,8 +287,8 @@ def test_mse_and_keras_adam(gpu):
 @pytest.mark.parametrize("n,coarse", [(1, True), (37, False), (4096, True), (100003, True)])
 def test_photometric_loss_in_one_launch(gpu, n, coarse):
     """training.photometric_loss (what train_step uses) against the oracle's img2mse / mse2psnr and
-    against img2mse + img2mse through the tape: loss, both terms, both PSNRs, both gradients; with
-    the tape's unit seed (no multiplication launched), with a weighted loss, and with grad_weight."""
+    against img2mse + img2mse through the tape: loss, both terms, both PSNRs, both gradients; plain,
+    with a weighted loss, and with grad_weight."""
     from nerf_amd import training
     from nerf_amd.run_nerf_helpers import img2mse
     from oracle import nerf_oracle as orc
