@@ -41,6 +41,8 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert b"nerf_sample_z" in lib.nerf_last_error()
     assert lib.nerf_mlp_forward_rays(None, None, 11, None, 1, 64, None, None) == -1
     assert lib.nerf_build_ray_batch(1, None, None, None, 0, 1, 1, 1.0, None, None, 0.0, 1.0, None, 9, None) == -1
+    assert lib.nerf_photometric_loss(None, None, None, 12, 1.0, None, None, None, None) == -1
+    assert b"nerf_photometric_loss" in lib.nerf_last_error()
     with pytest.raises(_native.NerfHipError):
         _native.check(-1, "probe")
 
@@ -54,6 +56,12 @@ def test_no_cpu_fallback():
         ops.get_rays(4, 4, 2.0, np.eye(4)[:3])
     with pytest.raises(_native.NerfHipError):
         ops.sample_z(torch.zeros((4, 11)), 8)
+    from nerf_amd import training
+    from nerf_amd.run_nerf_helpers import img2mse
+    with pytest.raises(_native.NerfHipError):
+        training.photometric_loss(torch.zeros((4, 3)), torch.zeros((4, 3)), torch.ones((4, 3)))
+    with pytest.raises(_native.NerfHipError):
+        img2mse(torch.zeros((4, 3)), torch.ones((4, 3)))
 
 
 def test_product_code_never_imports_the_oracle():
