@@ -17,6 +17,21 @@ def world():
     return 0, 1
 
 
+# A process group of ONE rank has nothing to exchange, and every function here returns early for
+# it.  With this set the collectives run all the same (and training.train_step takes its
+# data-parallel branch): the sums and gathers are identities, but the backend, its streams, work
+# handles and buffers are the real ones, which is how a machine with one GPU takes the RCCL path.
+EXCHANGE_WHEN_ALONE = False
+
+
+def exchanging():
+    """True when the collectives have to run: a process group is up and has more than one rank
+    (or EXCHANGE_WHEN_ALONE is set)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or EXCHANGE_WHEN_ALONE
+
+
 def shard_bounds(n, rank, world_size):
     """Contiguous slice [lo, hi) of n rays owned by `rank`; shards differ by at most one ray."""
     base, rem = divmod(n, world_size)
@@ -43,7 +58,7 @@ def gather_rows(local, n_total, group=None):
     """All-gathers per-ray rows [n_local, ...] from every rank into [n_total, ...] in ray order.
     Shards may differ in length by one, so each is padded to the longest before the collective."""
     _, w = world()
-    if w == 1:
+    if not exchanging():
         return local
     longest = (n_total + w - 1) // w
     pad = longest - local.shape[0]
@@ -112,8 +127,7 @@ def seed_sampling(seed):
 
 def broadcast_int(value, src=0):
     """The integer `value` of rank `src` on every rank (e.g. the step a run resumes from)."""
-    _, w = world()
-    if w == 1:
+    if not exchanging():
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64)
     if dist.get_backend() == "nccl":
@@ -127,8 +141,7 @@ def global_count(n_local, device=None):
     tensor on `device`: one tiny collective and no host synchronisation (the optimisation loop must
     not wait for the GPU every step); 1-rank jobs need no collective."""
     t = torch.tensor(float(n_local), dtype=torch.float64, device=device)
-    _, w = world()
-    if w > 1:
+    if exchanging():
         allreduce_sum_(t)
     return t
 
@@ -138,8 +151,7 @@ def allreduce_sum_(flat, async_op=False, group=None):
     one collective -- over xGMI the cost is latency, so never one call per tensor).  Each rank's
     loss must already be divided by the GLOBAL ray count so that the sum is the gradient of the
     global mean (run_nerf.py:781,:809-811).  Returns the work handle when async_op."""
-    _, w = world()
-    if w == 1:
+    if not exchanging():
         return None
     if flat.is_cuda and dist.get_backend() == "gloo":  # see _staged: through the host, synchronously
         host = flat.cpu()
@@ -162,8 +174,7 @@ def broadcast_parameters(models, src=0):
     resume from as well (broadcast_int); the optimiser is created after it with zero moments and
     iteration 0 on every rank -- the reference never reloads its state (run_nerf.py:244-261) --
     so nothing of it needs to travel."""
-    _, w = world()
-    if w == 1:
+    if not exchanging():
         return
     for m in models:
         with torch.no_grad():

@@ -62,7 +62,7 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
 
     from . import parallel
     rank, world_size = parallel.world()
-    if shard_over_ranks and world_size > 1:
+    if shard_over_ranks and parallel.exchanging():
         n_all = rays_flat.shape[0]
         lo, hi = parallel.shard_bounds(n_all, rank, world_size)
         per_ray = ('perturb_u', 'pdf_u', 'noise0', 'noise1')

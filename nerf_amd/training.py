@@ -377,8 +377,7 @@ def dp_loss_weight(n_local, device=None):
     """n_local / n_global: what a rank multiplies its local MEAN loss by.  A python float on one
     rank; a 0-d fp32 tensor on `device` otherwise (formed from an all-reduced count, never read
     back to the host)."""
-    _, world_size = parallel.world()
-    if world_size == 1:
+    if not parallel.exchanging():
         return 1.0
     n_global = parallel.global_count(n_local, device)
     return (float(n_local) / n_global.clamp_min(1.)).to(torch.float32)
@@ -393,8 +392,7 @@ def allreduce_gradients(grads, step=None):
     step=_DPStep (what train_step passes): the buffers were or are exchanged together with the
     step's [n_local x loss, n_local] tail, exchanges already started by the backward nodes are only
     waited for, every sum is divided by the summed ray count; returns (list, global mean loss)."""
-    rank, world_size = parallel.world()
-    if world_size == 1:
+    if not parallel.exchanging():
         return grads if step is None else (grads, None)
     from .run_nerf_helpers import NerfModel
     done = {}
@@ -449,7 +447,7 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
     the ranks with [n_local x loss, n_local] behind it and divided by the summed ray count, and
     the returned loss is the global mean (psnr / psnr0 are those of the local shard)."""
     global _DP_STEP
-    _, world_size = parallel.world()
+    alone = not parallel.exchanging()
     n_local = int(target_s.shape[0]) if hasattr(target_s, 'shape') else len(target_s)
     with GradientTape() as tape:
         rgb, disp, acc, extras = render_fn(batch_rays)
@@ -457,8 +455,8 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
         # data-parallel rank's gradient carries its ray count (the sums over the ranks are divided
         # by the summed count)
         loss, _, _, psnr, psnr0 = photometric_loss(rgb, extras.get('rgb0'), target_s,
-                                                   grad_weight=1.0 if world_size == 1 else float(n_local))
-    if world_size == 1:
+                                                   grad_weight=1.0 if alone else float(n_local))
+    if alone:
         gradients = tape.gradient(loss, grad_vars)
     else:
         step = _DPStep(n_local, loss, loss.device)

@@ -649,3 +649,82 @@ def test_data_parallel_train_step_two_ranks(gpu, tmp_path):
     s.close()
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def _rccl_alone_worker(rank, port, tmp):
+    """A process group of ONE rank over RCCL: with parallel.EXCHANGE_WHEN_ALONE the data-parallel
+    paths run through the real backend (broadcast of the replicas, the all-reduce started inside
+    the backward pass on RCCL's stream and waited for before the optimiser, the all-gather of a
+    sharded render) and, the exchanges being identities, must reproduce the plain paths bit for bit
+    (a batch of 1024 rays: the ray-count weight is a power of two)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from nerf_amd import parallel, training
+    from nerf_amd.run_nerf import create_nerf, render
+    from tests.util import default_args
+    torch.cuda.set_device(0)
+    gpu = torch.device("cuda", 0)
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+        probe = torch.ones(4, device=gpu)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    except Exception as e:  # no RCCL on this machine: nothing to test
+        open(os.path.join(tmp, "unavailable"), "w").write(repr(e))
+        return
+    try:
+        n = 1024
+        rb = synthetic_rays(n, seed=13)
+        rng = np.random.default_rng(17)
+        o, d = _t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)
+        target = _t(rng.uniform(size=(n, 3)).astype(np.float32), gpu)
+        pu = _t(rng.uniform(size=(n, 64)).astype(np.float32), gpu)
+        uu = _t(rng.uniform(size=(n, 128)).astype(np.float32), gpu)
+
+        def run(exchange):
+            parallel.EXCHANGE_WHEN_ALONE = exchange
+            assert parallel.exchanging() == exchange
+            torch.manual_seed(99)
+            kw_train, kw_test, _, grad_vars, models = create_nerf(default_args(white_bkgd=True, perturb=1.))
+            opt = training.Adam(training.ExponentialDecay(5e-4, 250 * 1000, 0.1))
+            fn = lambda r: render(1, 1, 1., chunk=1024 * 32, rays=r, near=2., far=6., retraw=True,
+                                  perturb_u=pu, pdf_u=uu, **kw_train)
+            out = [training.train_step(fn, (o, d), target, grad_vars, opt) for _ in range(3)]
+            losses = [float(l) for l, _, _ in out]
+            weights = [models[k].flat.detach().clone() for k in ('model', 'model_fine')]
+            with torch.no_grad():
+                rgb, disp, acc, extras = render(1, 1, 1., chunk=300, rays=(o, d), near=2., far=6., **kw_test)
+                if exchange:
+                    rgb_s, disp_s, acc_s, extras_s = parallel.render(1, 1, 1., chunk=300, rays=(o, d), near=2., far=6., **kw_test)
+                    assert torch.equal(rgb_s, rgb) and torch.equal(disp_s, disp) and torch.equal(acc_s, acc)
+                    assert sorted(extras_s) == sorted(extras) and all(torch.equal(extras_s[k], extras[k]) for k in extras)
+            return losses, weights, rgb
+        plain = run(False)
+        over_rccl = run(True)
+        assert plain[0] == over_rccl[0], (plain[0], over_rccl[0])
+        assert plain[0][-1] < plain[0][0]
+        for a, b in zip(plain[1], over_rccl[1]):
+            assert torch.equal(a, b), float((a - b).abs().max())
+        assert torch.equal(plain[2], over_rccl[2])
+        open(os.path.join(tmp, "ok"), "w").write("ok")
+    finally:
+        parallel.EXCHANGE_WHEN_ALONE = False
+        dist.destroy_process_group()
+
+
+def test_data_parallel_paths_over_rccl_with_one_rank(gpu, tmp_path):
+    """The collectives of the product (replica broadcast, in-backward all-reduce, sharded-render
+    all-gather) on the RCCL backend itself, which needs one GPU per rank: a one-rank group."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_alone_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    if os.path.exists(tmp_path / "unavailable"):
+        pytest.skip("RCCL process group could not be created here: " + open(tmp_path / "unavailable").read())
+    assert os.path.exists(tmp_path / "ok")
