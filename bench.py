@@ -98,6 +98,9 @@ def pmc_traffic_per_launch(kernel="mlp_fwd_wide_kernel<0, false,", summary=None)
     return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], f"{name}, same kernel sources"
 
 
+GROUPED = False  # a process group is up (more than one rank, or the one-rank RCCL rehearsal)
+
+
 def backend_is_rccl():
     import torch.distributed as dist
     return dist.get_backend() == "nccl"
@@ -182,7 +185,7 @@ def train_leg(a, kw_train, models, dev, rank, world, fence):
         loss, _, _ = training.train_step(fn, (o, d), target, grad_vars, opt)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if GROUPED:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX) if backend_is_rccl() else t.copy_(_max_over_ranks_on_host(t))
@@ -237,7 +240,7 @@ def strong_leg(a, kw_test, dev, rank, world, fence):
         parallel.gather_rows(packed, n)
     fence()
     dg = time.perf_counter() - t1
-    if world > 1:
+    if GROUPED:
         import torch.distributed as dist
         t = torch.tensor([dt, dg], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX) if backend_is_rccl() else t.copy_(_max_over_ranks_on_host(t))
@@ -279,10 +282,16 @@ def main():
     backend = os.environ.get("NERF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(0 if share_gpu else local_rank)
     dev = torch.device("cuda", 0 if share_gpu else local_rank)
+    # NERF_BENCH_RCCL_ALONE=1 (one process, one GPU): a ONE-rank RCCL group whose collectives are made
+    # to run, so that a one-GPU box walks the multi-rank code paths over the real backend.
+    global GROUPED
+    rccl_alone = world == 1 and os.environ.get("NERF_BENCH_RCCL_ALONE", "0") == "1"
+    GROUPED = world > 1 or rccl_alone
     dist = None
-    if world > 1:
+    if GROUPED:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -290,6 +299,7 @@ def main():
 
     from nerf_amd import ops, parallel
     from nerf_amd.run_nerf import create_nerf, render
+    parallel.EXCHANGE_WHEN_ALONE = rccl_alone
 
     torch.manual_seed(rank)  # every rank draws its own initial weights; create_nerf broadcasts rank 0's
     kw_train, kw_test, _, _, models = create_nerf(make_args())
@@ -297,12 +307,12 @@ def main():
     o, d = synthetic_batch(a.rays, 1000 + rank, dev)
     def step():
         rgb, disp, acc, _ = render(1, 1, 1., chunk=a.chunk, rays=(o, d), near=2., far=6., **kw_test)
-        if world > 1:  # the packed maps of every rank, in rank order (one all-gather, 20 B/ray)
+        if GROUPED:  # the packed maps of every rank, in rank order (one all-gather, 20 B/ray)
             parallel.gather_rows(torch.cat([rgb, disp[:, None], acc[:, None]], -1), world * a.rays)
         return rgb
 
     def fence():
-        if world > 1:
+        if GROUPED:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -318,7 +328,7 @@ def main():
     dt = time.perf_counter() - t0
     timing, ops.MLP_TIMING = ops.MLP_TIMING, None
     hbm_timing, ops.HBM_TIMING = ops.HBM_TIMING, None
-    if world > 1:
+    if GROUPED:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX) if backend_is_rccl() else t.copy_(_max_over_ranks_on_host(t))
         dt = float(t.item())
@@ -387,7 +397,7 @@ def main():
                              "networks": out["config"]["networks"], "parallelism": f"ray-sharded x{world}"}
             out["weak_1M"] = {"rays_per_s": round(rays_per_s, 1), "ms_per_step": round(dt / a.steps * 1e3, 3)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if GROUPED:
         dist.destroy_process_group()
 
 
