@@ -438,6 +438,31 @@ def test_render_rays_single_call_equals_stagewise(gpu, Sc, Si, lindisp, white, r
         assert torch.equal(torch.nan_to_num(one[k], nan=-1.), torch.nan_to_num(six[k], nan=-1.)), k
 
 
+def test_renders_on_two_streams_do_not_share_intermediates(gpu):
+    """Two ray batches rendered on two torch streams, enqueued back to back so that they are in
+    flight together, give the bits of the same renders made one after the other: the one-call
+    path keeps its intermediates in a workspace per (device, stream)."""
+    from nerf_amd import nerf_renderer, ops
+    args = default_args(white_bkgd=True)
+    kw_train, kw_test, _, models, wc, wf = _nets(args, 31)
+    kw = {k: v for k, v in kw_test.items() if k not in ('ndc', 'use_viewdirs')}
+    batches = [_t(synthetic_rays(n, seed=s), gpu) for n, s in ((4001, 41), (2503, 43))]
+    want = [nerf_renderer.render_rays(b, **kw) for b in batches]   # also packs the weights, on the current stream
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu) for _ in batches]
+    got = []
+    for b, st in zip(batches, streams):
+        with torch.cuda.stream(st):
+            got.append(nerf_renderer.render_rays(b, **kw))
+    torch.cuda.synchronize()
+    for b, st in zip(batches, streams):          # a workspace of its own per stream
+        assert (b.device, st.cuda_stream) in ops._RENDER_WS
+    assert len({ops._RENDER_WS[(b.device, st.cuda_stream)].data_ptr() for b, st in zip(batches, streams)}) == 2
+    for w, g in zip(want, got):
+        for k in w:
+            assert torch.equal(torch.nan_to_num(w[k], nan=-1.), torch.nan_to_num(g[k], nan=-1.)), k
+
+
 # ---- the whole loop on a scene with a known answer ---------------------------------------------------
 def test_trains_an_analytic_scene_end_to_end(gpu):
     """Twelve 32x32 views of a unit sphere coloured by its normal on a white background (rendered
