@@ -175,11 +175,14 @@ int nerf_render_rays(const void* packed_coarse, const void* packed_fine, const f
  * library runs on holds until the process ends; a call whose
  * nerf_render_rays_workspace_bytes(n_rays, N_samples, N_importance) exceeds it is rejected with
  * NERF_E_UNSUPPORTED before anything is launched (about 12,000 rays at 64 + 128 samples).  The call
- * allocates and frees nothing.  The first call on a GPU looks the array's address up, which makes
- * the HIP runtime load the code object that holds it on that GPU (the GPU's free memory drops by
- * the array's size at that moment, once); a call with n_rays == 0 does just that set-up, for
- * callers that want it out of the way before they start capturing or serving.  All calls on one GPU share the array: calls that overlap in time on
- * one GPU (different streams or threads) race; calls on one stream, or on different GPUs, do not. */
+ * allocates and frees nothing.  What the HIP runtime does by itself the first time something of a
+ * code object is used on a GPU is another matter: it loads that code object there, and the GPU's
+ * free memory drops (by the array's size when the array's address is first looked up, by a few MiB
+ * when a kernel of another source file is first launched).  A call with n_rays == 0 does exactly
+ * that and nothing else, for the array and for every kernel a call launches: callers make it once
+ * per GPU before they start capturing or serving, and no later call changes the GPU's free memory.
+ * All calls on one GPU share the array: calls that overlap in time on one GPU (different streams
+ * or threads) race; calls on one stream, or on different GPUs, do not. */
 size_t nerf_render_rays_static_bytes(void);
 int nerf_render_rays_static(const void* packed_coarse, const void* packed_fine, const float* rays, int width,
                             int64_t n_rays, int N_samples, int N_importance, int lindisp, int white_bkgd,

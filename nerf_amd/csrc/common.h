@@ -44,6 +44,23 @@ inline int device_cu_count() {
     return cus[dev];
 }
 
+// Makes the runtime load, on the current device, the code object that holds `kernel` (HIP loads a
+// translation unit's device code when something in it is first used, and takes device memory for
+// it then): set-up paths of entry points that promise to allocate nothing call it for every unit
+// whose kernels they will launch.
+template <class K>
+inline int preload_code_of(K kernel, const char* what) {
+    hipFuncAttributes attr;
+    const hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel));
+    if (e != hipSuccess) return NERF_FAIL((int)e, "%s: loading the device code: %s", what, hipGetErrorString(e));
+    return 0;
+}
+// One per translation unit whose kernels nerf_render_rays launches.
+int preload_rays_code(const char* what);
+int preload_mlp_forward_code(const char* what);
+int preload_composite_code(const char* what);
+int preload_sample_pdf_code(const char* what);
+
 constexpr int kWave = 64;
 
 template <int CTRL, int ROW_MASK>

@@ -317,6 +317,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     }
 }
 
+int preload_composite_code(const char* what) { return preload_code_of(composite_fwd_kernel<3, 1>, what); }
+
 }  // namespace nerf
 
 using namespace nerf;

@@ -660,6 +660,10 @@ static int launch_fwd_wide(FwdWideArgs a, int mode, hipStream_t st, const char* 
     return check_launch(what);
 }
 
+int preload_mlp_forward_code(const char* what) {
+    return preload_code_of(mlp_fwd_wide_kernel<0, false, NERF_FWD_WAVES, NERF_FWD_NPT>, what);
+}
+
 }  // namespace nerf
 
 using namespace nerf;

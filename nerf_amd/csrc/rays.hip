@@ -174,6 +174,8 @@ __global__ void sample_z_kernel(int64_t n, int S, const float* __restrict__ rays
 
 static inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+int preload_rays_code(const char* what) { return preload_code_of(sample_z_kernel, what); }
+
 }  // namespace nerf
 
 using namespace nerf;

@@ -135,10 +135,16 @@ NERF_API int nerf_render_rays_static(const void* packed_coarse, const void* pack
     int rc = check_render_args("nerf_render_rays_static", packed_coarse, rays, width, n_rays, N_samples, N_importance, rgb_map);
     if (rc) return rc;
     if (n_rays == 0) {
-        // set-up only: the code object that holds the array is loaded on the current device now (the
-        // device's free memory drops by the array's size here, once, and by nothing in later calls)
+        // set-up only: the code object that holds the array, and those of the kernels a call
+        // launches, are loaded on the current device now (the device's free memory drops by the
+        // array's size and a few MiB of code here, once, and by nothing in later calls)
         char* ws = nullptr;
-        return static_scratch(&ws);
+        rc = static_scratch(&ws);
+        if (!rc) rc = preload_rays_code("nerf_render_rays_static");
+        if (!rc) rc = preload_mlp_forward_code("nerf_render_rays_static");
+        if (!rc) rc = preload_composite_code("nerf_render_rays_static");
+        if (!rc) rc = preload_sample_pdf_code("nerf_render_rays_static");
+        return rc;
     }
     const size_t need = nerf_render_rays_workspace_bytes(n_rays, N_samples, N_importance);
     if (need > kStaticScratchBytes)

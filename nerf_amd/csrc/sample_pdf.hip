@@ -265,6 +265,8 @@ static int launch_pdf(PdfArgs a, bool merge, hipStream_t st, const char* what) {
     return check_launch(what);
 }
 
+int preload_sample_pdf_code(const char* what) { return preload_code_of(sample_pdf_kernel<true, 1>, what); }
+
 }  // namespace nerf
 
 using namespace nerf;

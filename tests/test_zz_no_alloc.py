@@ -88,3 +88,41 @@ def test_render_rays_static_matches_workspace_form(gpu):
                                      *[nv.ptr(o) for o in out], nv.stream())
     assert rc == -2 and b"built-in array" in lib.nerf_last_error()
     assert bool(torch.isinf(out[0]).all())
+
+
+def test_render_rays_static_under_graph_capture(gpu):
+    """What the entry point is for: captured into a HIP graph (where nothing may allocate) after the
+    one set-up call, then replayed twice on fresh inputs written into the captured buffers; each
+    replay gives the bits of the workspace form."""
+    from nerf_amd import _native as nv
+    from nerf_amd.run_nerf import create_nerf
+    lib = nv.lib()
+    kw_train, kw_test, _, _, models = create_nerf(default_args(white_bkgd=True))
+    rng = np.random.default_rng(6)
+    models['model'].set_weights(trained_like_weights(rng))
+    models['model_fine'].set_weights(trained_like_weights(rng))
+    pc, pf = models['model'].packed(), models['model_fine'].packed()
+    Sc, Si, n = 64, 128, 3000
+    rays = _t(synthetic_rays(n, seed=21), gpu)
+    new = lambda *s: torch.full(s, float('inf'), dtype=torch.float32, device=gpu)
+    out = [new(n, 3), new(n), new(n), new(n), new(n, 3), new(n), new(n), new(n)]
+    args = [nv.ptr(pc), nv.ptr(pf), nv.ptr(rays), 11, n, Sc, Si, 0, 1, None, None] + [nv.ptr(o) for o in out]
+    # set-up outside the capture (n_rays = 0 loads the array's code object on this GPU)
+    nv.check(lib.nerf_render_rays_static(*(args[:4] + [0] + args[5:]), nv.stream()), "nerf_render_rays_static(set-up)")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        nv.check(lib.nerf_render_rays_static(*args, nv.stream()), "nerf_render_rays_static(capture)")
+    assert bool(torch.isinf(out[0]).all())            # captured, not run
+    for seed in (21, 22):
+        rays.copy_(_t(synthetic_rays(n, seed=seed), gpu))
+        for o in out:
+            o.fill_(float('inf'))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = [torch.empty_like(o) for o in out]
+        ws = torch.empty((int(lib.nerf_render_rays_workspace_bytes(n, Sc, Si)),), dtype=torch.uint8, device=gpu)
+        nv.check(lib.nerf_render_rays(*(args[:11] + [nv.ptr(w) for w in want]), nv.ptr(ws), nv.stream()), "nerf_render_rays")
+        torch.cuda.synchronize()
+        for g, w in zip(out, want):
+            assert _same(g, w)
