@@ -307,7 +307,9 @@ def _model_from(ws, gpu):
 def _check_raw(raw, ref):
     """rgb after the sigmoid within 2e-3; sigma (pre-relu, unbounded) relative to its scale."""
     raw = raw.astype(np.float64)
-    sig = lambda v: 1. / (1. + np.exp(-v))
+    def sig(v):   # the logistic function without an overflowing exponential
+        e = np.exp(-np.abs(v))
+        return np.where(v >= 0, 1. / (1. + e), e / (1. + e))
     e_rgb = np.max(np.abs(sig(raw[..., :3]) - sig(ref[..., :3])))
     e_sig = np.max(np.abs(raw[..., 3] - ref[..., 3])) / max(1., float(np.max(np.abs(ref[..., 3]))))
     assert e_rgb < RGB_TOL, f"rgb error {e_rgb}"
@@ -354,7 +356,9 @@ def test_mlp_forward_away_from_glorot_scale(gpu, scale_hidden, alpha_scale, sigm
     m_rgb, m_sig = float(np.max(np.abs(ref[..., :3]))), float(np.max(np.abs(ref[..., 3])))
     e_pre = float(np.max(np.abs(raw[..., :3] - ref[..., :3])))
     e_sig = float(np.max(np.abs(raw[..., 3] - ref[..., 3])))
-    sig = lambda v: 1. / (1. + np.exp(-v))
+    def sig(v):   # the logistic function without an overflowing exponential
+        e = np.exp(-np.abs(v))
+        return np.where(v >= 0, 1. / (1. + e), e / (1. + e))
     e_rgb = float(np.max(np.abs(sig(raw[..., :3]) - sig(ref[..., :3]))))
     print(f"scale {scale_hidden} alpha x{alpha_scale}: max|rgb_pre| {m_rgb:.3g} max|sigma| {m_sig:.3g} "
           f"err rgb_pre {e_pre:.3g} sigma {e_sig:.3g} sigmoid(rgb) {e_rgb:.3g}")

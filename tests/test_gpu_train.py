@@ -254,7 +254,7 @@ def test_mse_and_keras_adam(gpu):
     y = rng.uniform(size=(1000, 3)).astype(np.float32)
     xt = _t(x, gpu).requires_grad_(True)
     loss = img2mse(xt, _t(y, gpu))
-    np.testing.assert_allclose(float(loss), orc.img2mse(x.astype(np.float64), y.astype(np.float64)), rtol=1e-5)
+    np.testing.assert_allclose(float(loss.detach()), orc.img2mse(x.astype(np.float64), y.astype(np.float64)), rtol=1e-5)
     (3.0 * loss).backward()
     np.testing.assert_allclose(xt.grad.cpu().numpy(), 3.0 * 2 * (x - y) / x.size, rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(float(mse2psnr(loss.detach())), orc.mse2psnr(float(loss)), rtol=1e-5)
