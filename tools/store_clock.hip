@@ -12,6 +12,8 @@
 //             space, never written), workgroups that run early fall back to counting.  The buffer
 //             holds HOLES times the dense bucket count; a k beyond it falls back to the fixed place
 //             in a second buffer (counted).
+//   clock/w   the same per WAVE: every wave reads the counter itself and takes slot (k, j, wave) of
+//             RUN KiB; nothing is shared between the waves of a workgroup (no LDS word, no barrier).
 // DRIFT > 0: workgroup b issues DRIFT * (b % 5) more MFMAs per store (workgroups out of step).
 // Every variant records where each (tile, layer) went; the host checks that no two share a place.
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/store_clock.hip -o tools/bin/store_clock
@@ -35,6 +37,7 @@ struct Args {
     long tiles;
     unsigned* counter;      // ticket mode: REGIONS counters, 4 KiB apart
     unsigned* table;        // [tile][LAYERS]: granule number in dst, or 0x80000000 | fixed granule in fallback
+    unsigned* wtable;       // per-wave mode: [tile][LAYERS][8]: slot of RUN KiB in dst, or 0x80000000 | fixed slot
     unsigned region_granules;
     const unsigned long long* t0;
     unsigned delta;         // clock ticks (10 ns) per bucket
@@ -56,14 +59,14 @@ __global__ __launch_bounds__(512) void place_kernel(Args a) {
     unsigned pending = 0;
     long k_prev = -1;
     unsigned fell = 0;
-    const unsigned long long t0 = MODE == 2 ? *a.t0 : 0ull;
+    const unsigned long long t0 = MODE >= 2 ? *a.t0 : 0ull;
     if (MODE == 1) {
         if (threadIdx.x == 0) pending = atomicAdd(a.counter + region * 1024, 1u);
     }
     int parity = 0;
     for (long tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
         for (int l = 0; l < LAYERS; ++l) {
-            if (MODE != 0) {
+            if (MODE == 1 || MODE == 2) {
                 if (threadIdx.x == 0) {
                     unsigned place;
                     if (MODE == 1) {
@@ -86,7 +89,21 @@ __global__ __launch_bounds__(512) void place_kernel(Args a) {
             }
             char* base;
             if (MODE == 0) base = a.dst + ((tile * 8 + wave) * LAYERS + l) * (long)RUN * 1024;
-            else {
+            else if (MODE == 3) {
+                // wave-uniform, nothing shared: this wave's own reading of the counter
+                const long k_clock = (long)((__builtin_amdgcn_s_memrealtime() - t0) / a.delta);
+                const long k = k_prev + 1 > k_clock ? k_prev + 1 : k_clock;
+                k_prev = k;
+                const unsigned long long g = ((unsigned long long)k * per_region + j) * 8 + wave;
+                const unsigned long long room = (unsigned long long)a.region_granules * 8;
+                const long fixed = (tile * LAYERS + l) * 8 + wave;
+                unsigned slot;
+                if (g < room) slot = (unsigned)(g + region * room);
+                else slot = 0x80000000u | (unsigned)fixed, ++fell;
+                if (lane == 0) a.wtable[fixed] = slot;
+                base = (slot & 0x80000000u) ? a.fallback + (long)(slot & 0x7fffffffu) * RUN * 1024
+                                            : a.dst + (long)slot * RUN * 1024;
+            } else {
                 const unsigned place = place_s[parity];
                 base = (place & 0x80000000u) ? a.fallback + ((long)(place & 0x7fffffffu) * GRAN + wave * RUN) * 1024
                                              : a.dst + ((long)place * GRAN + wave * RUN) * 1024;
@@ -100,7 +117,7 @@ __global__ __launch_bounds__(512) void place_kernel(Args a) {
             parity ^= 1;
         }
     }
-    if (MODE == 2 && threadIdx.x == 0) a.overflow[blockIdx.x] = fell, a.kmax[blockIdx.x] = (unsigned)k_prev;
+    if (MODE >= 2 && threadIdx.x == 0) a.overflow[blockIdx.x] = fell, a.kmax[blockIdx.x] = (unsigned)k_prev;
     if (acc[0] == 12345.f) a.sink[threadIdx.x] = acc[0];
 }
 
@@ -131,7 +148,7 @@ int main() {
     Args a{};
     unsigned long long* t0;
     if (hipMalloc(&a.dst, placed_bytes) != hipSuccess || hipMalloc(&a.fallback, fixed_bytes) != hipSuccess ||
-        hipMalloc(&a.counter, REGIONS * 4096) != hipSuccess || hipMalloc(&a.table, dense * 4) != hipSuccess ||
+        hipMalloc(&a.counter, REGIONS * 4096) != hipSuccess || hipMalloc(&a.table, dense * 4) != hipSuccess || hipMalloc(&a.wtable, dense * 8 * 4) != hipSuccess ||
         hipMalloc(&a.overflow, grid * 4) != hipSuccess || hipMalloc(&a.kmax, grid * 4) != hipSuccess ||
         hipMalloc(&a.sink, 4096) != hipSuccess || hipMalloc(&t0, 8) != hipSuccess) {
         printf("allocation failed\n");
@@ -161,6 +178,24 @@ int main() {
         printf("\n");
         return dup == 0 && oob == 0;
     };
+    std::vector<unsigned> wtable(dense * 8);
+    auto check_waves = [&]() {
+        (void)hipMemcpy(wtable.data(), a.wtable, dense * 8 * 4, hipMemcpyDeviceToHost);
+        std::vector<unsigned> s(wtable);
+        std::sort(s.begin(), s.end());
+        long dup = 0, oob = 0, fb = 0;
+        for (long i = 1; i < dense * 8; ++i) dup += s[i] == s[i - 1];
+        for (long i = 0; i < dense * 8; ++i) {
+            if (s[i] & 0x80000000u) ++fb;
+            else if (s[i] >= (unsigned long long)region_granules * 8 * REGIONS) ++oob;
+        }
+        (void)hipMemcpy(km.data(), a.kmax, grid * 4, hipMemcpyDeviceToHost);
+        unsigned kmx = 0;
+        for (int i = 0; i < grid; ++i) kmx = std::max(kmx, km[i]);
+        printf("   slots: %ld duplicates, %ld out of range, %ld of %ld fell back, last bucket (wave 0) %u of %ld dense\n", dup, oob, fb,
+               dense * 8, kmx, dense / grid);
+        return dup == 0 && oob == 0;
+    };
     bool ok = true;
 #define SET(M, D)                                                                                                   \
     {                                                                                                               \
@@ -178,6 +213,9 @@ int main() {
             snprintf(name, sizeof name, "clock buckets of %u ticks (%d %% of a layer), " #M " MFMA per store, drift " #D, a.delta, pct); \
             run5(name, gb, [&] { stamp_kernel<<<1, 1>>>(t0); place_kernel<2, M, D><<<grid, 512>>>(a); });           \
             ok &= check(true);                                                                                      \
+            snprintf(name, sizeof name, "  the same per wave (nothing shared in a workgroup), %u ticks", a.delta);  \
+            run5(name, gb, [&] { stamp_kernel<<<1, 1>>>(t0); place_kernel<3, M, D><<<grid, 512>>>(a); });           \
+            ok &= check_waves();                                                                                    \
         }                                                                                                           \
     }
     SET(0, 0)
