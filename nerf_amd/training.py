@@ -109,10 +109,15 @@ class MLPQuery(torch.autograd.Function):
         for p in model.params:
             grads.append(flat[at:at + p.numel()].view(p.shape))
             at += p.numel()
-        model.review_grad_status()
+        # (under graph capture the host cannot look at a status block: GraphedTrainStep does both
+        # calls around its replays instead)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            model.review_grad_status()
         gscale = model.grad_scale if model.grad_scale is not None else -float(model.auto_target)
         ops.mlp_backward(model.packed_bwd(), ctx.act, d_raw, gscale, gbuf, partial, grads)
-        model.post_grad_status()
+        if not capturing:
+            model.post_grad_status()
         ctx.act = None
         model._grad_work = None
         if once and _DP_STEP is not None:
@@ -468,3 +473,85 @@ def train_step(render_fn, batch_rays, target_s, grad_vars, optimizer, models=())
         gradients, loss = allreduce_gradients(gradients, step)
     optimizer.apply_gradients(zip(gradients, grad_vars))
     return loss.detach(), psnr, psnr0
+
+
+class GraphedTrainStep:
+    """train_step for one batch size with the forward and backward passes of both networks captured
+    into ONE HIP graph and replayed.  A step is some fifty kernel launches issued through Python,
+    about 1.2 ms of host time whatever the batch: batches of a thousand rays or fewer finish on the
+    GPU before the host has enqueued them, and the captured step takes the host out of it.  (At the
+    reference's default of 4096 rays the GPU is the longer side either way.)
+
+        step = GraphedTrainStep(render_fn, N_rand, grad_vars, optimizer, [model, model_fine])
+        loss, psnr, psnr0 = step(batch_rays, target_s)       # as train_step returns them
+
+    render_fn(rays) must call render(..., rays=rays, **render_kwargs_train); batch_rays is the
+    (rays_o, rays_d) pair of [N_rand, 3] tensors.  The batch is copied into the graph's own input
+    buffers; the returned tensors are the graph's outputs and hold their values until the next call.
+    The optimiser step runs outside the graph (its learning rate changes every step and is a
+    kernel argument).  The automatic fp16 gradient scale keeps looking after itself: the status
+    blocks are read between replays, and the step is captured anew when a network's target moved.
+    Single process only (no gradient exchange inside the graph)."""
+
+    def __init__(self, render_fn, n_rays, grad_vars, optimizer, models, device=None):
+        if parallel.exchanging():
+            raise NotImplementedError("GraphedTrainStep: single process only; use train_step under torch.distributed")
+        self.render_fn, self.grad_vars, self.optimizer = render_fn, list(grad_vars), optimizer
+        self.models = list(models)
+        if not self.models:
+            raise ValueError("GraphedTrainStep: pass the networks the step trains")
+        dev = torch.device(device) if device is not None else self.models[0].device
+        self.device = dev
+        new = lambda: torch.zeros((int(n_rays), 3), dtype=torch.float32, device=dev)
+        self.rays, self.target = (new(), new()), new()
+        self.captures = 0
+        self.graph = self.out = self._targets = None
+
+    def _fwd_bwd(self):
+        with GradientTape() as tape:
+            rgb, disp, acc, extras = self.render_fn(self.rays)
+            loss, _, _, psnr, psnr0 = photometric_loss(rgb, extras.get('rgb0'), self.target)
+        return loss, psnr, psnr0, tape.gradient(loss, self.grad_vars)
+
+    def _capture(self):
+        # (the parameters' gradient-accumulation nodes were made on whatever stream first used the
+        # parameters; tape.gradient never accumulates into them, so torch's warning about their
+        # stream does not apply here)
+        warn = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if warn is not None:
+            warn(False)
+        try:
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):   # un-captured passes first: the nodes' reusable buffers, lazy set-up
+                for _ in range(2):
+                    self._fwd_bwd()
+            cur.wait_stream(side)
+            for m in self.models:           # the graph packs the weights itself, at every replay
+                m.mark_dirty()
+            self._targets = [(m.grad_scale, m.auto_target) for m in self.models]
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._fwd_bwd()
+        finally:
+            if warn is not None:
+                warn(True)
+        self.captures += 1
+
+    def __call__(self, batch_rays, target_s):
+        rays_o, rays_d = batch_rays
+        with torch.no_grad():
+            self.rays[0].copy_(nv.f32(rays_o, self.device).reshape(-1, 3))
+            self.rays[1].copy_(nv.f32(rays_d, self.device).reshape(-1, 3))
+            self.target.copy_(nv.f32(target_s, self.device).reshape(-1, 3))
+        for m in self.models:
+            m.review_grad_status()
+        if self.graph is None or self._targets != [(m.grad_scale, m.auto_target) for m in self.models]:
+            self._capture()
+        self.graph.replay()
+        for m in self.models:
+            m.post_grad_status()
+        loss, psnr, psnr0, grads = self.out
+        self.optimizer.apply_gradients(zip(grads, self.grad_vars))
+        return loss.detach(), psnr, psnr0

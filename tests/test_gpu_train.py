@@ -651,6 +651,55 @@ def test_data_parallel_train_step_two_ranks(gpu, tmp_path):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
+def test_graphed_train_step_equals_train_step(gpu):
+    """GraphedTrainStep (forward + backward of both networks as one HIP graph, replayed) against
+    train_step on the same batches and uniforms: the same weights bit for bit after four steps;
+    a moved gradient-scale target makes it capture anew; with its own random streams it trains."""
+    from nerf_amd import training
+    from nerf_amd.run_nerf import create_nerf, render
+    from tests.util import default_args
+    n = 300
+    rng = np.random.default_rng(23)
+    batches = [(synthetic_rays(n, seed=50 + i), rng.uniform(size=(n, 3)).astype(np.float32)) for i in range(4)]
+    pu, uu = _t(rng.uniform(size=(n, 64)), gpu), _t(rng.uniform(size=(n, 128)), gpu)
+
+    def setup():
+        torch.manual_seed(7)
+        kw_train, _, _, grad_vars, models = create_nerf(default_args(white_bkgd=True, perturb=1.))
+        opt = training.Adam(training.ExponentialDecay(5e-4, 250 * 1000, 0.1))
+        fn = lambda r: render(1, 1, 1., chunk=1024 * 32, rays=r, near=2., far=6., retraw=True,
+                              perturb_u=pu, pdf_u=uu, **kw_train)
+        return kw_train, grad_vars, models, opt, fn
+    kw_train, grad_vars, models, opt, fn = setup()
+    eager = [training.train_step(fn, (_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)), _t(tg, gpu), grad_vars, opt) for rb, tg in batches]
+    eager_losses = [float(l) for l, _, _ in eager]
+    want = [models[k].flat.detach().clone() for k in ('model', 'model_fine')]
+    kw_train, grad_vars, models, opt, fn = setup()
+    step = training.GraphedTrainStep(fn, n, grad_vars, opt, [models['model'], models['model_fine']])
+    got_losses = []
+    for rb, tg in batches:
+        loss, psnr, psnr0 = step((_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)), _t(tg, gpu))
+        got_losses.append(float(loss))
+        np.testing.assert_allclose(float(psnr), -10. * np.log10(float(loss) - 10 ** (-float(psnr0) / 10.)), rtol=1e-3)
+    assert step.captures == 1 and opt.iterations == 4
+    assert got_losses == eager_losses, (got_losses, eager_losses)
+    for k, w in zip(('model', 'model_fine'), want):
+        assert torch.equal(models[k].flat, w), k
+    # a moved target (what review_grad_status does after a saturated pass) is a kernel argument: captured anew
+    models['model_fine'].auto_target = 16.0
+    rb, tg = batches[0]
+    loss, _, _ = step((_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)), _t(tg, gpu))
+    assert step.captures == 2 and np.isfinite(float(loss))
+    flags, gs, mx = models['model_fine'].grad_status()
+    assert flags == 0 and 16. <= gs * mx < 32.
+    # free-running (torch.rand inside the graph: new uniforms at every replay) on one batch: the loss falls
+    kw_train, grad_vars, models, opt, _ = setup()
+    fn_rand = lambda r: render(1, 1, 1., chunk=1024 * 32, rays=r, near=2., far=6., retraw=True, **kw_train)
+    step = training.GraphedTrainStep(fn_rand, n, grad_vars, opt, [models['model'], models['model_fine']])
+    losses = [float(step((_t(rb[:, :3], gpu), _t(rb[:, 3:6], gpu)), _t(tg, gpu))[0]) for _ in range(40)]
+    assert losses[-1] < 0.9 * losses[0] and len(set(losses)) == 40, losses[::8]
+
+
 def _rccl_alone_worker(rank, port, tmp):
     """A process group of ONE rank over RCCL: with parallel.EXCHANGE_WHEN_ALONE the data-parallel
     paths run through the real backend (broadcast of the replicas, the all-reduce started inside
