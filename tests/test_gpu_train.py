@@ -257,7 +257,7 @@ def test_mse_and_keras_adam(gpu):
     np.testing.assert_allclose(float(loss.detach()), orc.img2mse(x.astype(np.float64), y.astype(np.float64)), rtol=1e-5)
     (3.0 * loss).backward()
     np.testing.assert_allclose(xt.grad.cpu().numpy(), 3.0 * 2 * (x - y) / x.size, rtol=1e-5, atol=1e-9)
-    np.testing.assert_allclose(float(mse2psnr(loss.detach())), orc.mse2psnr(float(loss)), rtol=1e-5)
+    np.testing.assert_allclose(float(mse2psnr(loss.detach())), orc.mse2psnr(float(loss.detach())), rtol=1e-5)
     # Keras Adam with the reference's decay schedule, 5 steps, against the oracle in float64
     theta0 = rng.normal(size=(5000,)).astype(np.float32)
     flat = _t(theta0, gpu)
