@@ -2,10 +2,11 @@
 RCCL over xGMI on MI355X; "gloo" in the CPU tests).
 
 Rays are independent, so the only exchanges are (a) an all-gather of the rendered maps at the end
-of a sharded render (20-24 B per ray) and (b) one all-reduce(SUM) of the 1,191,688-float gradient
-of both networks per training step (4.77 MB: latency-bound over xGMI, so it is sent as ONE flat
-bucket rather than 48 small tensors).  Nothing here touches the kernels, so the same code runs on
-CPU tensors under gloo.
+of a sharded render (20-24 B per ray) and (b) one all-reduce(SUM) per network and training step of
+the network's flat gradient buffer (595,844 floats = 2.38 MB, with the step's loss and ray count in
+two more floats behind it: latency-bound over xGMI, so it travels as ONE buffer rather than 24 small
+tensors, and the fine network's exchange runs beside the coarse network's backward pass).  Nothing
+here touches the kernels, so the same code runs on CPU tensors under gloo.
 """
 import torch
 import torch.distributed as dist
