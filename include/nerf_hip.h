@@ -272,7 +272,9 @@ int nerf_mse_loss_fwd_bwd(const float* x, const float* y, int64_t count, float i
  * psnr, psnr0 (overwritten, nothing to zero; out[2] = out[4] = 0 without rgb0);
  * d_rgb = grad_weight * d loss / d rgb, d_rgb0 likewise (either may be NULL).  grad_weight is 1 for
  * a single process; a data-parallel rank passes its ray count (see the gradient exchange of
- * nerf_mlp_backward's callers: gradients are summed over the ranks and divided by the summed count). */
+ * nerf_mlp_backward's callers: gradients are summed over the ranks and divided by the summed count).
+ * One workgroup does it all (deterministic sums, no atomics): meant for a step's ray batch, a few
+ * thousand to a few hundred thousand scalars; nerf_mse_loss_fwd_bwd spreads larger inputs over the chip. */
 int nerf_photometric_loss(const float* rgb, const float* rgb0, const float* target, int64_t count,
                           float grad_weight, float* out, float* d_rgb, float* d_rgb0, nerf_stream_t stream);
 

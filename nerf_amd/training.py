@@ -541,6 +541,9 @@ class GraphedTrainStep:
 
     def __call__(self, batch_rays, target_s):
         rays_o, rays_d = batch_rays
+        n = self.target.shape[0]
+        if nv.f32(target_s, self.device).reshape(-1, 3).shape[0] != n:
+            raise ValueError(f"GraphedTrainStep: captured for batches of {n} rays")
         with torch.no_grad():
             self.rays[0].copy_(nv.f32(rays_o, self.device).reshape(-1, 3))
             self.rays[1].copy_(nv.f32(rays_d, self.device).reshape(-1, 3))
