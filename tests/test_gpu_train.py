@@ -308,19 +308,19 @@ def test_photometric_loss_in_one_launch(gpu, n, coarse):
         scale = weight * (outer or 1.0)
         np.testing.assert_allclose(gx.cpu().numpy(), scale * 2 * (f64(x) - y) / x.size, rtol=2e-6, atol=1e-12)
         if coarse:
-            np.testing.assert_allclose(float(loss), want + want0, rtol=1e-5)
+            np.testing.assert_allclose(float(loss.detach()), want + want0, rtol=1e-5)
             np.testing.assert_allclose(float(img_loss0), want0, rtol=1e-5)
             np.testing.assert_allclose(float(psnr0), orc.mse2psnr(want0), rtol=1e-5, atol=1e-5)
             np.testing.assert_allclose(gx0.cpu().numpy(), scale * 2 * (f64(x0) - y) / x.size, rtol=2e-6, atol=1e-12)
         else:
-            np.testing.assert_allclose(float(loss), want, rtol=1e-5)
+            np.testing.assert_allclose(float(loss.detach()), want, rtol=1e-5)
             assert img_loss0 is None and psnr0 is None and not bool(gx0.any())
     # the two-node form a caller's own loop would write gives the same numbers
     xt, x0t = _t(x, gpu).requires_grad_(True), _t(x0, gpu).requires_grad_(True)
     with training.GradientTape() as tape:
         loss2 = img2mse(xt, _t(y, gpu)) + img2mse(x0t, _t(y, gpu))
     hx, hx0 = tape.gradient(loss2, [xt, x0t])
-    np.testing.assert_allclose(float(loss2), want + want0, rtol=1e-5)
+    np.testing.assert_allclose(float(loss2.detach()), want + want0, rtol=1e-5)
     np.testing.assert_allclose(hx.cpu().numpy(), 2 * (f64(x) - y) / x.size, rtol=2e-6, atol=1e-12)
     np.testing.assert_allclose(hx0.cpu().numpy(), 2 * (f64(x0) - y) / x.size, rtol=2e-6, atol=1e-12)
     # same inputs, same bits (one workgroup, no atomics)
